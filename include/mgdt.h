@@ -1,0 +1,125 @@
+/* mgdt.h - C ABI of the MI355X-native MGDT-YOLO detection hot path (libmgdt_hip.so).
+ *
+ * Every entry point: plain pointers/sizes, no torch types, asynchronous on the caller's hipStream_t,
+ * never allocates or frees device memory (the caller owns inputs, outputs, packed weights and
+ * workspaces), returns 0 on success or a negative mgdt_status; mgdt_last_error() gives the text
+ * (thread-local).  No host synchronisation inside, except where noted.
+ *
+ * Activations are addressed through `mgdt_view`: an NHWC-ordered 4-d view with explicit element
+ * strides, so channel slices of a wider tensor (the reference's chunk()/split()/cat() on dim 1) and
+ * torch channels_last tensors are passed without copies.
+ *
+ * Each function cites the reference interface (paths relative to the reference repo root) it replaces.
+ */
+#ifndef MGDT_H
+#define MGDT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mgdt_stream; /* hipStream_t */
+
+typedef enum { MGDT_OK = 0, MGDT_BAD_SHAPE = -1, MGDT_BAD_DTYPE = -2, MGDT_LAUNCH_FAIL = -3, MGDT_BAD_ARG = -4,
+               MGDT_WORKSPACE = -5 } mgdt_status;
+typedef enum { MGDT_F32 = 0, MGDT_BF16 = 1 } mgdt_dtype;
+typedef enum { MGDT_ACT_NONE = 0, MGDT_ACT_SILU = 1, MGDT_ACT_RELU = 2, MGDT_ACT_GELU = 3 } mgdt_act;
+
+/* 4-d activation view; sizes in elements, strides in elements of `dtype`. p may be NULL for "absent". */
+typedef struct {
+  void* p;
+  int32_t n, h, w, c;
+  int64_t sn, sh, sw, sc;
+} mgdt_view;
+
+const char* mgdt_last_error(void);
+const char* mgdt_version(void);
+
+/* ---- weight packing: nn.Conv2d weight (OIHW fp32) [+ BatchNorm2d fold] -> MFMA fragment order ----------
+ * Replaces yolo/utils/torch_utils.py:114-135 (fuse_conv_and_bn) + the implicit weight layout of ATen conv2d.
+ * bn_* may all be NULL (no BN; conv_bias optional).  With BN: W' = diag(g/sqrt(var+eps)) W,
+ * b' = beta - g*mean/sqrt(var+eps) (+ scaled conv bias).  Outputs: packed weights (size from
+ * mgdt_conv_packed_bytes) and bias_out[cout_pad] fp32 (cout rounded up to 16).                          */
+size_t mgdt_conv_packed_bytes(int cin, int cout, int k, int dtype);
+int mgdt_conv_pack(const float* w_oihw, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                   const float* bn_mean, const float* bn_var, float bn_eps, int cin, int cout, int k, int dtype,
+                   void* packed_out, float* bias_out, mgdt_stream s);
+
+/* ---- fused convolution (implicit GEMM on MFMA) ------------------------------------------------------------
+ * Replaces nn/modules/conv.py:25-42 Conv.forward/forward_fuse (conv2d + folded BN + act), the Bottleneck
+ * shortcut add (nn/modules/block.py:514-526), the MSPA pre-add `sp + spx[i]` (block.py:252-254), the
+ * channel-slice reads/writes that stand in for chunk()/cat() (block.py:203-207,250-266), nn.Linear on NHWC
+ * tokens (convnextv2.py:59,62) and GRN's per-(image,channel) affine on the input (utils.py:171-182).
+ *   y = act( conv(k, stride, pad=k/2)( (x [+ x2]) [* in_scale[n,c] + in_shift[c]] ) + bias ) [+ r1] [+ r2]
+ * groups == 1, k in {1,3}, stride in {1,2}, cin % (4 fp32 | 8 bf16) == 0, all views sc == 1.               */
+int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
+                    const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
+                    const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s);
+
+/* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
+ * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
+ * w_gemm: [k*k*cin/groups][cout] fp32 from mgdt_conv_pack_direct; bias fp32[cout].                         */
+int mgdt_conv_pack_direct(const float* w_oihw, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
+                          const float* bn_mean, const float* bn_var, float bn_eps, int cin_g, int cout, int k,
+                          float* w_out, float* bias_out, mgdt_stream s);
+int mgdt_conv2d_direct_fwd(const mgdt_view* x, int x_dtype, const float* w_gemm, const float* bias, int k, int stride,
+                           int groups, int act, const mgdt_view* y, int dtype, mgdt_stream s);
+
+/* ---- MSPA attention: SPRModule pooling + MLP + softmax over the 4 groups + scale ------------------------
+ * nn/modules/spr_module.py:8-31, nn/modules/block.py:268-287.
+ * pool: x (n,h,w,c) -> pooled fp32 [n][MGDT_SPR_SPLITS][c][5]: per row-band partial SUMS of {whole map, the four
+ *       adaptive_avg_pool2d(2) bins (row-major)} (fixed reduction order: results are run-to-run identical);
+ * attn: finishes the means, runs fc1/ReLU/fc2/sigmoid on each of the `groups` channel groups (shared weights,
+ *       fc1_w [cw/4][5cw], fc2_w [cw][cw/4], cw = c/groups), softmax over the groups -> attn fp32 [n][c];
+ * scale: y = x * attn[n,c].                                                                               */
+#define MGDT_SPR_SPLITS 16
+int mgdt_spr_pool_fwd(const mgdt_view* x, float* pooled, int dtype, mgdt_stream s);
+int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                      const float* fc2_b, int n, int c, int groups, int h, int w, float* attn, mgdt_stream s);
+int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, const mgdt_view* y, int dtype, mgdt_stream s);
+
+/* ---- SPPF pooling: y1,y2,y3 = maxpool5(x), maxpool5(y1), maxpool5(y2) (nn/modules/block.py:138-153) ----- */
+int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const mgdt_view* y2, const mgdt_view* y3, int dtype,
+                       mgdt_stream s);
+
+/* ---- resamplers (nn/modules/block.py:292,304,316,328,393-394; nn.Upsample in models/v8/yolov8.yaml) ---- */
+int mgdt_adaptive_avgpool_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
+int mgdt_bilinear_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s); /* align_corners=False */
+int mgdt_nearest_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
+int mgdt_copy_fwd(const mgdt_view* x, int x_dtype, const mgdt_view* y, int y_dtype, mgdt_stream s); /* cat / layout / cast */
+
+/* ---- ConvNeXtV2 block pieces (nn/modules/convnextv2.py:48-77, nn/modules/utils.py:145-182) -------------
+ * dwln: y = LayerNorm_c(dwconv7x7(x) + b) * ln_w + ln_b   (eps 1e-6), dw_w is [49][c] fp32.
+ * grn_stats: t (n,h,w,c) -> scale[n][c] = gamma[c]*Nx[n,c] + 1, with Nx = ||t||_2(h,w) / (mean_c + 1e-6);
+ *            ws: fp32 [n][c] scratch.  (shift[c] = beta[c] is passed to mgdt_conv2d_fwd directly.)        */
+int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                        float eps, const mgdt_view* y, int dtype, mgdt_stream s);
+int mgdt_grn_stats_fwd(const mgdt_view* t, const float* gamma, float* ws, float* scale, int dtype, mgdt_stream s);
+
+/* ---- InjectionMultiSum_Auto_pool tail (nn/modules/block.py:381-399) --------------------------------------
+ * up branch  (local >= global size): y = local * bilinear(relu6(ga+3)/6) + bilinear(gf)
+ * pool branch (local <  global size): y = local * avgpool(ga) + avgpool(gf)   (no h_sigmoid, as written)  */
+int mgdt_inject_fwd(const mgdt_view* local, const mgdt_view* ga, const mgdt_view* gf, const mgdt_view* y, int dtype,
+                    mgdt_stream s);
+
+/* ---- Detect eval tail (nn/modules/head.py:165-177; DFL block.py:36-54; tal.py:476-500) ------------------
+ * feat: one level (n,h,w,4R+nc) raw head map; writes y[n][4+nc][a_total] at anchor offset a_off:
+ * xywh = dist2bbox(softmax_R . arange(R), anchor(+0.5)) * stride, cls = sigmoid.  y is fp32.              */
+int mgdt_detect_decode_fwd(const mgdt_view* feat, int reg_max, int nc, float stride, int a_off, int a_total, float* y,
+                           int dtype, mgdt_stream s);
+
+/* ---- batched NMS (yolo/utils/ops.py:136-266 incl. the torchvision.ops.nms call at :249) -----------------
+ * pred fp32 [n][4+nc][a].  Outputs per image: out[n][max_det][6] fp32 rows (x1,y1,x2,y2,conf,cls),
+ * kept_anchor[n][max_det] int32 (anchor index of each kept row), counts[n] int32.  classes: optional int32
+ * list (NULL = all).  Ties in score: lower candidate index first.  ws from mgdt_nms_workspace_bytes.       */
+size_t mgdt_nms_workspace_bytes(int n, int nc, int a, int multi_label, int max_nms);
+int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, float iou_thres, const int32_t* classes,
+                 int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
+                 int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGDT_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libmgdt_hip.so (the C ABI declared in include/mgdt.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmgdt_hip.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+SPR_SPLITS = 16
+
+
+class View(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
+                ('sn', C.c_int64), ('sh', C.c_int64), ('sw', C.c_int64), ('sc', C.c_int64)]
+
+
+VP = C.POINTER(View)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/mgdt.h declares (tests check this)
+PROTOTYPES = {
+    'mgdt_last_error': (C.c_char_p, []),
+    'mgdt_version': (C.c_char_p, []),
+    'mgdt_conv_packed_bytes': (_sz, [_i, _i, _i, _i]),
+    'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
+    'mgdt_conv_pack_direct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    'mgdt_conv2d_direct_fwd': (_i, [VP, _i, _vp, _vp, _i, _i, _i, _i, VP, _i, _vp]),
+    'mgdt_spr_pool_fwd': (_i, [VP, _vp, _i, _vp]),
+    'mgdt_spr_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'mgdt_scale_channels_fwd': (_i, [VP, _vp, VP, _i, _vp]),
+    'mgdt_sppf_pool_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
+    'mgdt_adaptive_avgpool_fwd': (_i, [VP, VP, _i, _vp]),
+    'mgdt_bilinear_fwd': (_i, [VP, VP, _i, _vp]),
+    'mgdt_nearest_fwd': (_i, [VP, VP, _i, _vp]),
+    'mgdt_copy_fwd': (_i, [VP, _i, VP, _i, _vp]),
+    'mgdt_dwconv7_ln_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, VP, _i, _vp]),
+    'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
+    'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
+    'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),
+    'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(mgdt_yolo_amd has no CPU or PyTorch fallback)')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status, what=''):
+    if status != 0:
+        raise RuntimeError(f'{what or "mgdt"} failed ({status}): {lib().mgdt_last_error().decode()}')

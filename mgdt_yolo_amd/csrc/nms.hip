@@ -1,0 +1,244 @@
+// Batched NMS, one workgroup per image, no host round trip (the reference loops over images in Python and
+// calls ~10 small ops + torchvision.ops.nms per image: yolo/utils/ops.py:199-264).
+//
+//   1. candidate predicate straight from pred[n][4+nc][a] (score > conf, best-class or multi-label, class filter)
+//   2. exact top-`max_nms` selection by MSD radix select on the 64-bit key (descending score, ascending
+//      candidate id = anchor*nc + cls)  -> deterministic tie rule "lower candidate index first"
+//   3. bitonic sort of the selected keys (LDS when <= 16384 keys, else an L2-resident global buffer)
+//   4. greedy suppression by one wavefront, 64 sorted candidates per step: every lane tests its box against
+//      the kept list (LDS broadcast reads), survivors are resolved inside the chunk with ballot + shuffles.
+//      The scan stops at max_det kept boxes (identical to nms(...)[:max_det]).
+// IoU arithmetic is the torchvision CPU kernel's, in IEEE fp32 with FP contraction off (this file is compiled
+// with -ffp-contract=off) on boxes offset by cls*max_wh in fp32 exactly as ops.py:247-248 does, so kept indices
+// are bit-exact with the CPU oracle.
+#include "common.h"
+
+#define NMS_THREADS 1024
+#define NMS_LDS_KEYS 16384
+typedef unsigned long long u64;
+
+struct NmsArgs {
+  const float* pred;
+  int n, nc, A;
+  float conf, iou;
+  const int32_t* classes;
+  int n_classes, agnostic, multi_label, max_det, max_nms;
+  float max_wh;
+  float* out;
+  int32_t* kept_anchor;
+  int32_t* counts;
+  u64* ws;          // per image: sort buffer [cap_pow2] (+ [A] best-class keys when !multi_label)
+  long ws_per_image;  // in u64
+  int cap_pow2;
+};
+
+__device__ __forceinline__ u64 make_key(float score, unsigned cand) {
+  return ((u64)(0xFFFFFFFFu - __float_as_uint(score)) << 32) | cand;   // scores are positive: bit order == value order
+}
+#define KEY_NONE 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ bool class_ok(int c, const int32_t* classes, int n_classes) {
+  if (!classes) return true;
+  for (int i = 0; i < n_classes; ++i)
+    if (classes[i] == c) return true;
+  return false;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const float* P = a.pred + (long)img * (4 + a.nc) * a.A;
+  u64* gbuf = a.ws + (long)img * a.ws_per_image;
+  u64* akeys = gbuf + a.cap_pow2;              // only used when !multi_label
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_cnt, s_sel;
+  __shared__ u64 s_prefix;
+
+  const long total = a.multi_label ? (long)a.A * a.nc : a.A;
+  // candidate key of flat index i (multi: i = c*A + anchor so that reads are anchor-contiguous)
+  auto key_at = [&](long i) -> u64 {
+    if (a.multi_label) {
+      int c = (int)(i / a.A), an = (int)(i - (long)c * a.A);
+      float sc = P[(long)(4 + c) * a.A + an];
+      if (sc > a.conf && class_ok(c, a.classes, a.n_classes)) return make_key(sc, (unsigned)an * a.nc + c);
+      return KEY_NONE;
+    }
+    return akeys[i];
+  };
+  if (!a.multi_label) {   // best class per anchor (first maximal index), ops.py:225-226
+    for (int an = tid; an < a.A; an += NMS_THREADS) {
+      float best = P[(long)4 * a.A + an];
+      int bc = 0;
+      for (int c = 1; c < a.nc; ++c) {
+        float sc = P[(long)(4 + c) * a.A + an];
+        if (sc > best) { best = sc; bc = c; }
+      }
+      akeys[an] = (best > a.conf && class_ok(bc, a.classes, a.n_classes)) ? make_key(best, (unsigned)an * a.nc + bc) : KEY_NONE;
+    }
+    __syncthreads();
+  }
+
+  // ---- count candidates
+  if (tid == 0) { s_cnt = 0; s_sel = 0; }
+  __syncthreads();
+  {
+    unsigned local = 0;
+    for (long i = tid; i < total; i += NMS_THREADS) local += key_at(i) != KEY_NONE;
+    atomicAdd(&s_cnt, local);
+  }
+  __syncthreads();
+  const unsigned ncand = s_cnt;
+  unsigned K = ncand < (unsigned)a.max_nms ? ncand : (unsigned)a.max_nms;
+
+  // ---- threshold key: the K-th smallest key (MSD radix select, 8 bits per pass), only when truncating
+  u64 kth = KEY_NONE - 1;   // select everything valid
+  if (ncand > K) {
+    u64 prefix = 0;
+    unsigned need = K;      // rank (1-based) of the wanted key among keys matching the prefix
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      for (int i = tid; i < 256; i += NMS_THREADS) hist[i] = 0;
+      __syncthreads();
+      const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+      for (long i = tid; i < total; i += NMS_THREADS) {
+        u64 k = key_at(i);
+        if (k != KEY_NONE && (k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned run = 0, b = 0;
+        for (; b < 256; ++b) {
+          if (run + hist[b] >= need) break;
+          run += hist[b];
+        }
+        s_prefix = prefix | ((u64)b << shift);
+        s_sel = need - run;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      need = s_sel;
+      __syncthreads();
+    }
+    kth = prefix;   // keys are unique (candidate id in the low word): exactly K keys are <= kth
+  }
+
+  // ---- compact the selected keys into the sort buffer (unordered), pad to a power of two
+  unsigned np2 = 1;
+  while (np2 < K) np2 <<= 1;
+  u64* sbuf = (np2 <= NMS_LDS_KEYS) ? (u64*)smem : gbuf;
+  if (tid == 0) s_sel = 0;
+  __syncthreads();
+  for (long i = tid; i < total; i += NMS_THREADS) {
+    u64 k = key_at(i);
+    if (k != KEY_NONE && k <= kth) sbuf[atomicAdd(&s_sel, 1u)] = k;
+  }
+  for (unsigned i = K + tid; i < np2; i += NMS_THREADS) sbuf[i] = KEY_NONE;
+  __syncthreads();
+
+  // ---- bitonic sort ascending (== descending score, ascending candidate id)
+  for (unsigned k2 = 2; k2 <= np2; k2 <<= 1) {
+    for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+      for (unsigned i = tid; i < np2; i += NMS_THREADS) {
+        unsigned ixj = i ^ j;
+        if (ixj > i) {
+          u64 x = sbuf[i], y = sbuf[ixj];
+          bool up = (i & k2) == 0;
+          if ((x > y) == up) { sbuf[i] = y; sbuf[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- greedy suppression by wave 0
+  float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
+  if (tid < 64) {
+    const int lane = tid;
+    const int md = a.max_det;
+    int nkept = 0;
+    for (unsigned base = 0; base < K && nkept < md; base += 64) {
+      unsigned idx = base + lane;
+      bool valid = idx < K;
+      u64 key = valid ? sbuf[idx] : KEY_NONE;
+      unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
+      int an = valid ? (int)(cand / (unsigned)a.nc) : 0, cls = valid ? (int)(cand % (unsigned)a.nc) : 0;
+      float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
+      float score = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
+      float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
+      float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
+      float bx1 = x1 + off, by1 = y1 + off, bx2 = x2 + off, by2 = y2 + off;
+      float area = (bx2 - bx1) * (by2 - by1);
+      bool alive = valid;
+      for (int k = 0; k < nkept; ++k) {   // LDS broadcast reads
+        float xx1 = fmaxf(kb[k], bx1), yy1 = fmaxf(kb[md + k], by1);
+        float xx2 = fminf(kb[2 * md + k], bx2), yy2 = fminf(kb[3 * md + k], by2);
+        float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+        float inter = iw * ih;
+        float ovr = inter / (kb[4 * md + k] + area - inter);
+        if (ovr > a.iou) alive = false;
+      }
+      u64 mask = __ballot(alive);
+      while (mask && nkept < md) {
+        int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
+        float ix1 = __shfl(bx1, i), iy1 = __shfl(by1, i), ix2 = __shfl(bx2, i), iy2 = __shfl(by2, i), iar = __shfl(area, i);
+        if (lane == i) {
+          kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
+          float* o = a.out + ((long)img * md + nkept) * 6;
+          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = score; o[5] = (float)cls;
+          a.kept_anchor[(long)img * md + nkept] = an;
+          alive = false;
+        }
+        if (alive && lane > i) {
+          float xx1 = fmaxf(ix1, bx1), yy1 = fmaxf(iy1, by1), xx2 = fminf(ix2, bx2), yy2 = fminf(iy2, by2);
+          float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+          float inter = iw * ih;
+          float ovr = inter / (iar + area - inter);
+          if (ovr > a.iou) alive = false;
+        }
+        ++nkept;
+        mask = __ballot(alive);
+      }
+    }
+    if (lane == 0) a.counts[img] = nkept;
+  }
+}
+
+static inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+extern "C" size_t mgdt_nms_workspace_bytes(int n, int nc, int a, int multi_label, int max_nms) {
+  long cand = multi_label ? (long)a * nc : a;
+  long cap = next_pow2((int)std::min<long>(cand, max_nms));
+  return (size_t)n * (cap + (multi_label ? 0 : a)) * sizeof(u64);
+}
+
+extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, float iou_thres, const int32_t* classes,
+                            int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
+                            int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s) {
+  if (!pred || !out || !kept_anchor || !counts || !ws) MGDT_FAIL(MGDT_BAD_ARG, "nms: null pointer");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f)) MGDT_FAIL(MGDT_BAD_ARG, "Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", conf_thres);
+  if (!(iou_thres >= 0.f && iou_thres <= 1.f)) MGDT_FAIL(MGDT_BAD_ARG, "Invalid IoU %g, valid values are between 0.0 and 1.0", iou_thres);
+  if (n < 1 || nc < 1 || a < 1 || max_det < 1 || max_nms < 1 || (long)a * nc > 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: n=%d nc=%d a=%d max_det=%d", n, nc, a, max_det);
+  multi_label = multi_label && nc > 1;   // ops.py:196
+  if (ws_bytes < mgdt_nms_workspace_bytes(n, nc, a, multi_label, max_nms)) MGDT_FAIL(MGDT_WORKSPACE, "nms: workspace too small");
+  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)5 * max_det * sizeof(float);
+  if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: max_det=%d too large for the LDS kept list", max_det);
+  NmsArgs g;
+  g.pred = pred; g.n = n; g.nc = nc; g.A = a; g.conf = conf_thres; g.iou = iou_thres; g.classes = n_classes > 0 ? classes : nullptr;
+  g.n_classes = n_classes; g.agnostic = agnostic; g.multi_label = multi_label; g.max_det = max_det; g.max_nms = max_nms;
+  g.max_wh = max_wh; g.out = out; g.kept_anchor = kept_anchor; g.counts = counts; g.ws = (u64*)ws;
+  long cand = multi_label ? (long)a * nc : a;
+  g.cap_pow2 = next_pow2((int)std::min<long>(cand, max_nms));
+  g.ws_per_image = g.cap_pow2 + (multi_label ? 0 : a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  nms_kernel<<<n, NMS_THREADS, lds, (hipStream_t)s>>>(g);
+  MGDT_CHECK_LAUNCH("nms_fwd");
+  return MGDT_OK;
+}

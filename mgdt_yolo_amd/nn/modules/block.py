@@ -1,0 +1,238 @@
+"""Block modules of the registry (reference: nn/modules/block.py), compute on MI355X via libmgdt_hip.so.
+
+The reference builds these from chunk()/cat()/elementwise torch ops; here every block pre-allocates its
+concatenated NHWC buffer once and lets the fused conv kernel read/write channel slices of it, so no
+concat, split or add is ever materialised.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .conv import Conv, HipModule
+from .convnextv2 import ConvNeXtV2_Block
+from .spr_module import SPRModule
+
+__all__ = ('DFL', 'SPPF', 'C2f', 'MSPA_C2f', 'Bottleneck', 'SimFusion_4in', 'SimFusion_3in', 'IFM', 'h_sigmoid',
+           'InjectionMultiSum_Auto_pool', 'Upsample')
+
+
+class DFL(nn.Module):
+    """Integral module of Distribution Focal Loss (reference block.py:36-54): parameter container; the
+    softmax-expectation is fused into the Detect decode kernel."""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+
+class Bottleneck(HipModule):
+    """Standard bottleneck (reference block.py:514-526); the shortcut add is the conv epilogue's residual."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        k0 = k[0][0] if isinstance(k[0], (tuple, list)) else k[0]
+        k1 = k[1][0] if isinstance(k[1], (tuple, list)) else k[1]
+        self.cv1 = Conv(c1, c_, k0, 1)
+        self.cv2 = Conv(c_, c2, k1, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def run(self, x, out=None, x2=None):
+        """y = [x (+x2)] + cv2(cv1(x (+x2))); `x2` is MSPA's pending `sp + spx[i]` add."""
+        t = self.cv1.run(x, x2=x2)
+        return self.cv2.run(t, out=out, r1=x if self.add else None, r2=x2 if self.add else None)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class C2f(HipModule):
+    """CSP bottleneck with 2 convolutions (reference block.py:187-207)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def forward(self, x):
+        b, _, h, w = x.shape
+        c, n = self.c, len(self.m)
+        cat = ops.new_act(b, (2 + n) * c, h, w, self.cv1.out_dtype(x), x.device)
+        self.cv1.run(x, out=cat[:, :2 * c])
+        for j, m in enumerate(self.m):
+            m.run(cat[:, (1 + j) * c:(2 + j) * c], out=cat[:, (2 + j) * c:(3 + j) * c])
+        return self.cv2.run(cat)
+
+    forward_split = forward
+
+
+class MSPA_C2f(HipModule):
+    """C2f with multi-scale pooling attention (reference block.py:209-287; scale=4, stride=1)."""
+
+    def __init__(self, inplanes, outplanes, n=1, shortcut=False, g=1, e=0.5, scale=4, stride=1, stype='normal'):
+        super().__init__()
+        self.nums = scale
+        self.inwidth = inplanes // self.nums
+        self.outwidth = outplanes // self.nums
+        self.stride = stride
+        assert stype in ['stage', 'normal'], 'One of these is suppported (stage or normal)'
+        self.stype = stype
+        self.convs = nn.ModuleList([])
+        self.btnk_nums = n
+        for i in range(self.nums):
+            if self.stride == 1 and i != self.nums - 1:
+                self.convs.append(Conv(self.inwidth, self.inwidth, 1, 1))
+            else:
+                self.convs.append(Conv(inplanes + self.outwidth * (n - 1), outplanes, 1, 1))
+        self.bottleneck = nn.ModuleList(Bottleneck(self.inwidth, self.inwidth, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+        self.attention = SPRModule(self.outwidth)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x):
+        if self.stride != 1:
+            raise RuntimeError('MSPA_C2f: only stride=1 is wired by parse_model and built here')
+        b, _, h, w = x.shape
+        wd, s, n = self.inwidth, self.nums, self.btnk_nums
+        cat = ops.new_act(b, (s - 1 + n) * wd, h, w, self.convs[0].out_dtype(x), x.device)
+        # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
+        self.convs[0].run(x[:, :wd], out=cat[:, :wd])
+        for i in range(1, s - 1):
+            self.convs[i].run(cat[:, (i - 1) * wd:i * wd], x2=x[:, i * wd:(i + 1) * wd], out=cat[:, i * wd:(i + 1) * wd])
+        # last group: chained bottlenecks, each output kept (block.py:260-263)
+        src, pending = cat[:, (s - 2) * wd:(s - 1) * wd], x[:, (s - 1) * wd:s * wd]
+        for j, m in enumerate(self.bottleneck):
+            dst = cat[:, (s - 1 + j) * wd:(s + j) * wd]
+            m.run(src, out=dst, x2=pending)
+            src, pending = dst, None
+        out = self.convs[s - 1].run(cat)
+        attn = self.attention.group_attention(out, s)            # softmax over the 4 groups, fp32 [B, C]
+        return ops.scale_channels(out, attn)
+
+
+class SPPF(HipModule):
+    """Spatial Pyramid Pooling - Fast (reference block.py:138-153); 5/9/13 max windows in one pass."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        if k != 5:
+            raise RuntimeError('SPPF: k=5 is what the YAMLs use and what the fused pooling kernel implements')
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)   # module-tree parity only
+
+    def forward(self, x):
+        b, _, h, w = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = ops.new_act(b, 4 * c_, h, w, self.cv1.out_dtype(x), x.device)
+        self.cv1.run(x, out=cat[:, :c_])
+        ops.sppf_pools(cat[:, :c_], cat[:, c_:2 * c_], cat[:, 2 * c_:3 * c_], cat[:, 3 * c_:])
+        return self.cv2.run(cat)
+
+
+class Upsample(nn.Module):
+    """nn.Upsample(None, 2, 'nearest') of the stock YAML (models/v8/yolov8.yaml:30,34) on device."""
+
+    def __init__(self, size=None, scale_factor=None, mode='nearest'):
+        super().__init__()
+        if mode != 'nearest' or size is not None:
+            raise RuntimeError("Upsample: only (None, scale_factor, 'nearest') is on the detection path")
+        self.scale_factor, self.mode, self.size = scale_factor, mode, size
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        out = ops.new_act(b, c, int(h * self.scale_factor), int(w * self.scale_factor), x.dtype, x.device)
+        return ops.nearest(x, out)
+
+
+class SimFusion_4in(nn.Module):
+    """FAM (reference block.py:289-307): resample 4 levels to the 3rd one's size and concatenate."""
+
+    def forward(self, x):
+        x_l, x_m, x_s, x_n = x
+        b, c, h, w = x_s.shape
+        cs = [x_l.shape[1], x_m.shape[1], c, x_n.shape[1]]
+        out = ops.new_act(b, sum(cs), h, w, x_s.dtype, x_s.device)
+        o = 0
+        ops.adaptive_avgpool(x_l, out[:, o:o + cs[0]]); o += cs[0]
+        ops.adaptive_avgpool(x_m, out[:, o:o + cs[1]]); o += cs[1]
+        ops.copy(x_s, out[:, o:o + cs[2]]); o += cs[2]
+        ops.bilinear(x_n, out[:, o:o + cs[3]])
+        return out
+
+
+class SimFusion_3in(HipModule):
+    """LAF (reference block.py:309-329)."""
+
+    def __init__(self, in_channel_list, out_channels):
+        super().__init__()
+        self.cv1 = Conv(in_channel_list[0], out_channels, act=nn.ReLU()) if in_channel_list[0] != out_channels else nn.Identity()
+        self.cv2 = Conv(in_channel_list[1], out_channels, act=nn.ReLU()) if in_channel_list[1] != out_channels else nn.Identity()
+        self.cv3 = Conv(in_channel_list[2], out_channels, act=nn.ReLU()) if in_channel_list[2] != out_channels else nn.Identity()
+        self.cv_fuse = Conv(out_channels * 3, out_channels, act=nn.ReLU())
+
+    def forward(self, x):
+        b, _, h, w = x[1].shape
+        oc = self.cv_fuse.conv.out_channels
+        dt, dev = x[1].dtype, x[1].device
+        cat = ops.new_act(b, 3 * oc, h, w, dt, dev)
+        # branch 0: adaptive avg-pool then (optional) 1x1 ReLU conv
+        if isinstance(self.cv1, nn.Identity):
+            ops.adaptive_avgpool(x[0], cat[:, :oc])
+        else:
+            self.cv1.run(ops.adaptive_avgpool(x[0], ops.new_act(b, x[0].shape[1], h, w, dt, dev)), out=cat[:, :oc])
+        if isinstance(self.cv2, nn.Identity):
+            ops.copy(x[1], cat[:, oc:2 * oc])
+        else:
+            self.cv2.run(x[1], out=cat[:, oc:2 * oc])
+        if isinstance(self.cv3, nn.Identity):
+            ops.bilinear(x[2], cat[:, 2 * oc:])
+        else:
+            self.cv3.run(ops.bilinear(x[2], ops.new_act(b, x[2].shape[1], h, w, dt, dev)), out=cat[:, 2 * oc:])
+        return self.cv_fuse.run(cat)
+
+
+class IFM(nn.Module):
+    """Information fusion module (reference block.py:331-342)."""
+
+    def __init__(self, inc, ouc, embed_dim_p=96, fuse_block_num=3) -> None:
+        super().__init__()
+        self.conv = nn.Sequential(Conv(inc, embed_dim_p), *[ConvNeXtV2_Block(embed_dim_p) for _ in range(fuse_block_num)],
+                                  Conv(embed_dim_p, sum(ouc)))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class h_sigmoid(nn.Module):
+    """relu6(x+3)/6 (reference block.py:344-350); fused into the Injection kernel."""
+
+    def __init__(self, inplace=True):
+        super().__init__()
+        self.relu = nn.ReLU6(inplace=inplace)
+
+
+class InjectionMultiSum_Auto_pool(HipModule):
+    """Information injection (reference block.py:352-399)."""
+
+    def __init__(self, inp: int, oup: int, global_inp: list, flag: int) -> None:
+        super().__init__()
+        self.global_inp = global_inp
+        self.flag = flag
+        self.local_embedding = Conv(inp, oup, 1, act=False)
+        self.global_embedding = Conv(global_inp[self.flag], oup, 1, act=False)
+        self.global_act = Conv(global_inp[self.flag], oup, 1, act=False)
+        self.act = h_sigmoid()
+
+    def forward(self, x):
+        x_l, x_g = x
+        c0 = sum(self.global_inp[:self.flag])
+        g = x_g[:, c0:c0 + self.global_inp[self.flag]]      # split(...)[flag] as a channel-slice view
+        local = self.local_embedding.run(x_l)
+        ga = self.global_act.run(g)
+        gf = self.global_embedding.run(g)
+        return ops.inject(local, ga, gf)                    # pool vs up-sample branch chosen from the shapes (block.py:369)

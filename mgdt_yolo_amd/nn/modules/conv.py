@@ -1,0 +1,130 @@
+"""Convolution modules of the registry (reference: nn/modules/conv.py), compute on MI355X via libmgdt_hip.so.
+
+Same class names, constructor signatures and parameter names as the reference (`conv.weight`,
+`bn.{weight,bias,running_mean,running_var}`), so YAML graphs and state_dicts transfer unchanged.
+nn.Conv2d / nn.BatchNorm2d objects are used as PARAMETER CONTAINERS only; their forward is never called.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+__all__ = ('Conv', 'DWConv', 'Concat', 'autopad')
+
+
+def autopad(k, p=None, d=1):
+    """'same' padding (reference nn/modules/conv.py:16-22)."""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def act_code(m):
+    if isinstance(m, nn.SiLU):
+        return ops.ACT_SILU
+    if isinstance(m, nn.ReLU):
+        return ops.ACT_RELU
+    if isinstance(m, nn.Identity):
+        return ops.ACT_NONE
+    if isinstance(m, nn.GELU):
+        return ops.ACT_GELU
+    raise RuntimeError(f'activation {type(m).__name__} has no fused HIP epilogue (SiLU, ReLU, GELU, Identity are built)')
+
+
+class HipModule(nn.Module):
+    """Base: compute dtype bookkeeping + packed-weight cache invalidated by parameter versions."""
+    _cdtype = None   # set by DetectionModel.set_compute_dtype(); None -> follow the input
+
+    def out_dtype(self, x):
+        return self._cdtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+
+    def _cached(self, key, tensors, build):
+        cache = self.__dict__.setdefault('_pk', {})
+        ver = tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, build())
+            cache[key] = hit
+        return hit[1]
+
+    @staticmethod
+    def _no_train_bn(m):
+        if m.training:
+            raise NotImplementedError('training-mode BatchNorm (batch statistics) + backward kernels are not built in this round; '
+                                      'call .eval() (raw head maps for the loss: model.model[-1].training = True)')
+
+
+class Conv(HipModule):
+    """Conv2d + BatchNorm2d + act (reference nn/modules/conv.py:25-42); BN folded at pack time (torch_utils.py:114-135)."""
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+
+    # -- packed weights ------------------------------------------------------------------------------
+    def _geometry(self):
+        c = self.conv
+        k, s = c.kernel_size[0], c.stride[0]
+        if c.kernel_size[0] != c.kernel_size[1] or c.stride[0] != c.stride[1] or c.dilation != (1, 1) or c.padding != (k // 2, k // 2):
+            raise RuntimeError(f'Conv geometry {c} is outside the built kernels (square k, same padding, dilation 1)')
+        return k, s
+
+    def packed(self, dtype, direct):
+        has_bn = hasattr(self, 'bn')
+        tens = [self.conv.weight, self.conv.bias] + ([self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var] if has_bn else [])
+        k, _ = self._geometry()
+
+        def build():
+            bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps) if has_bn else None
+            return ops.PackedConv(self.conv.weight, self.conv.bias, bn, k, dtype, direct=direct, groups=self.conv.groups)
+        return self._cached((dtype, direct), tens, build)
+
+    # -- compute ----------------------------------------------------------------------------------------
+    def run(self, x, out=None, x2=None, r1=None, r2=None, in_scale=None, in_shift=None):
+        if hasattr(self, 'bn'):
+            self._no_train_bn(self.bn)
+        k, s = self._geometry()
+        dt = self.out_dtype(x) if out is None else out.dtype
+        mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
+        pk = self.packed(dt, direct=not mfma)
+        return ops.conv2d(x, pk, s, act_code(self.act), out=out, x2=x2, r1=r1, r2=r2, in_scale=in_scale, in_shift=in_shift)
+
+    def forward(self, x):
+        return self.run(x)
+
+    def forward_fuse(self, x):
+        """After BaseModel.fuse(): `bn` is gone and `conv` carries the folded weight + bias (conv.py:40-42)."""
+        return self.run(x)
+
+
+class DWConv(Conv):
+    """Depth-wise convolution (reference conv.py:82-86): registry entry, direct kernel."""
+
+    def __init__(self, c1, c2, k=1, s=1, d=1, act=True):
+        super().__init__(c1, c2, k, s, g=math.gcd(c1, c2), d=d, act=act)
+
+
+class Concat(nn.Module):
+    """Concatenate along a dimension (reference conv.py:287-297); channel concat of NHWC maps on device."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        if self.d != 1:
+            raise RuntimeError('Concat: only channel concatenation (dimension=1) is on the detection path')
+        b, _, h, w = x[0].shape
+        out = ops.new_act(b, sum(t.shape[1] for t in x), h, w, x[0].dtype, x[0].device)
+        c0 = 0
+        for t in x:
+            ops.copy(t, out[:, c0:c0 + t.shape[1]])
+            c0 += t.shape[1]
+        return out

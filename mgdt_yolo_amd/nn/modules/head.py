@@ -1,0 +1,82 @@
+"""Detect head (reference: nn/modules/head.py:133-186), compute on MI355X via libmgdt_hip.so.
+
+Per level the box branch (3x3, 3x3, 1x1+bias -> 4*reg_max) and the class branch (3x3, 3x3, 1x1+bias -> nc) write
+straight into the two channel ranges of one (B, no, H, W) NHWC map (the reference's torch.cat at head.py:160).
+Eval: one decode kernel per level does DFL softmax-expectation + dist2bbox + stride scaling + sigmoid and
+writes y (B, 4+nc, A) fp32.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .block import DFL
+from .conv import Conv, HipModule
+
+__all__ = ('Detect',)
+
+
+class _HeadConv(HipModule):
+    """The head's final `nn.Conv2d(c, out, 1)` with bias: parameter container + packed 1x1 MFMA conv."""
+
+    @staticmethod
+    def run(owner, conv, x, out):
+        pk = owner._cached((id(conv), out.dtype), [conv.weight, conv.bias],
+                           lambda: ops.PackedConv(conv.weight, conv.bias, None, 1, out.dtype))
+        return ops.conv2d(x, pk, 1, ops.ACT_NONE, out=out)
+
+
+class Detect(HipModule):
+    """YOLOv8 Detect head for detection models (this fork: reg_max = 4, head.py:145)."""
+    dynamic = False
+    export = False
+    shape = None
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 4
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], self.nc)
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+
+    def forward(self, x):
+        """Train: list of (B, no, H, W) raw maps.  Eval: (y (B, 4+nc, A), that list).  Mutates the input list in place
+        like the reference (head.py:160)."""
+        shape = x[0].shape
+        r4 = 4 * self.reg_max
+        for i in range(self.nl):
+            xi = x[i]
+            b, _, h, w = xi.shape
+            feat = ops.new_act(b, self.no, h, w, self.cv2[i][0].out_dtype(xi), xi.device)
+            t = self.cv2[i][1].run(self.cv2[i][0].run(xi))
+            _HeadConv.run(self, self.cv2[i][2], t, feat[:, :r4])
+            t = self.cv3[i][1].run(self.cv3[i][0].run(xi))
+            _HeadConv.run(self, self.cv3[i][2], t, feat[:, r4:])
+            x[i] = feat
+        if self.training:
+            return x
+        if self.dynamic or self.shape != shape:
+            from ...yolo.utils.tal import make_anchors
+            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, self.stride, 0.5))
+            self.shape = shape
+        a_total = sum(f.shape[2] * f.shape[3] for f in x)
+        y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
+        a_off = 0
+        for i, f in enumerate(x):
+            ops.detect_decode(f, self.reg_max, self.nc, float(self.stride[i]), a_off, y)
+            a_off += f.shape[2] * f.shape[3]
+        return y if self.export else (y, x)
+
+    def bias_init(self):
+        """Initialize Detect() biases (reference head.py:179-186); requires stride availability."""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[:self.nc] = math.log(5 / self.nc / (640 / s) ** 2)

@@ -1,0 +1,260 @@
+"""Model graph / registry layer (reference: nn/tasks.py): `DetectionModel`, `parse_model`, `yaml_model_load`.
+
+Same call surface as the reference's `tasks.DetectionModel` so the engine side (trainer / validator / predictor
+counterparts) drives it as a drop-in:
+  model(x: Tensor)  -> (y, feats) in eval, feats in train;  model(batch: dict) -> (loss*B, loss_items[3])
+  .yaml .names .nc .args .stride .model (nn.Sequential) .save .inplace, .fuse() .info() .load() .init_criterion()
+All per-layer compute runs in libmgdt_hip.so; there is no CPU or ATen fallback (CPU tensors raise).
+"""
+import ast
+import contextlib
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..yolo.utils.torch_utils import fuse_conv_and_bn, initialize_weights, intersect_dicts, make_divisible
+from .modules import (C2f, IFM, MSPA_C2f, SPPF, Bottleneck, Concat, Conv, Detect, DWConv, InjectionMultiSum_Auto_pool,
+                      SimFusion_3in, SimFusion_4in, Upsample)
+
+# names a YAML row may use -> class (the reference resolves them with globals()[m] / getattr(torch.nn, ...), tasks.py:630)
+REGISTRY = {c.__name__: c for c in (Conv, DWConv, Concat, Bottleneck, C2f, MSPA_C2f, SPPF, SimFusion_4in, SimFusion_3in, IFM,
+                                    InjectionMultiSum_Auto_pool, Detect)}
+REGISTRY['nn.Upsample'] = Upsample
+
+
+class BaseModel(nn.Module):
+    """Reference: nn/tasks.py BaseModel (:28-216)."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):   # training / validating-while-training: batch dict -> loss (tasks.py:44-45)
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False):
+        if augment or profile or visualize:
+            raise RuntimeError('augment / profile / visualize are host-side tooling outside the hot path')
+        return self._predict_once(x)
+
+    def _predict_once(self, x, profile=False, visualize=False):
+        """Per-layer dispatch with the save-list (tasks.py:65-87)."""
+        if not x.is_cuda:
+            raise RuntimeError('mgdt_yolo_amd runs on MI355X (HIP) only: move the model and the input to cuda (no CPU fallback)')
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self, verbose=True):
+        """Fold BatchNorm into the conv parameters and drop the bn modules (tasks.py:121-146)."""
+        if not self.is_fused():
+            for m in self.model.modules():
+                if isinstance(m, (Conv, DWConv)) and hasattr(m, 'bn'):
+                    m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                    delattr(m, 'bn')
+                    m.forward = m.forward_fuse
+                    m.__dict__.pop('_pk', None)
+        return self
+
+    def is_fused(self, thresh=10):
+        bn = tuple(v for k, v in nn.__dict__.items() if 'Norm' in k)
+        return sum(isinstance(v, bn) for v in self.modules()) < thresh
+
+    def info(self, detailed=False, verbose=True, imgsz=640):
+        n_p = sum(x.numel() for x in self.parameters())
+        n_l = len(list(self.modules()))
+        if verbose:
+            print(f'{Path(self.yaml.get("yaml_file", "model")).stem} summary: {n_l} layers, {n_p} parameters')
+        return n_l, n_p
+
+    def _apply(self, fn):
+        """Move the head's stride / anchor tensors with the module (tasks.py:171-188)."""
+        self = super()._apply(fn)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = fn(m.stride)
+            m.anchors = fn(m.anchors)
+            m.strides = fn(m.strides)
+        return self
+
+    def load(self, weights, verbose=True):
+        """Transfer name+shape matching entries of a checkpoint / module / state_dict (tasks.py:190-202)."""
+        model = weights['model'] if isinstance(weights, dict) and 'model' in weights else weights
+        csd = model.float().state_dict() if isinstance(model, nn.Module) else {k: v.float() for k, v in model.items()}
+        csd = intersect_dicts(csd, self.state_dict())
+        self.load_state_dict(csd, strict=False)
+        if verbose:
+            print(f'Transferred {len(csd)}/{len(self.model.state_dict())} items from pretrained weights')
+
+    def loss(self, batch, preds=None):
+        if not hasattr(self, 'criterion'):
+            self.criterion = self.init_criterion()
+        preds = self.forward(batch['img']) if preds is None else preds
+        return self.criterion(preds, batch)
+
+    def init_criterion(self):
+        raise NotImplementedError('compute_loss() needs to be implemented by task heads')
+
+    # -- MI355X-specific knobs (not in the reference) ------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        """float32 (exact path, 1e-3 box parity) or bfloat16 (throughput path); parameters stay fp32 masters."""
+        ops.dtype_code(dtype)
+        for m in self.modules():
+            if hasattr(m, 'out_dtype'):
+                m._cdtype = dtype
+        self.compute_dtype = dtype
+        return self
+
+
+class DetectionModel(BaseModel):
+    """YOLOv8 detection model (reference tasks.py:222-294)."""
+
+    def __init__(self, cfg='yolov8n.yaml', ch=3, nc=None, verbose=True):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml['ch'] = self.yaml.get('ch', ch)
+        if nc and nc != self.yaml['nc']:
+            self.yaml['nc'] = nc
+        self.model, self.save, reductions = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f'{i}' for i in range(self.yaml['nc'])}
+        self.inplace = self.yaml.get('inplace', True)
+        self.compute_dtype = torch.float32
+        self.args = None
+
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.inplace = self.inplace
+            # The reference probes strides with a 640^2 zero image on the CPU (tasks.py:241-245).  There is no CPU
+            # compute here, so the same numbers come from the graph: stride = total down-sampling of each head input.
+            m.stride = torch.tensor([float(reductions[j]) for j in m.f])
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        initialize_weights(self)
+        if verbose:
+            self.info()
+
+    def init_criterion(self):
+        from ..yolo.utils.loss import v8DetectionLoss
+        return v8DetectionLoss(self)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def parse_model(d, ch, verbose=True):
+    """YAML dict -> nn.Sequential + save-list, with the reference's argument-rewriting rules (tasks.py:604-699).
+    Also returns each layer's cumulative spatial reduction (for the head strides)."""
+    max_channels = float('inf')
+    nc, act, scales = (d.get(x) for x in ('nc', 'activation', 'scales'))
+    depth, width = (d.get(x, 1.0) for x in ('depth_multiple', 'width_multiple'))
+    if scales:
+        scale = d.get('scale')
+        if not scale:
+            scale = tuple(scales.keys())[0]
+            print(f"WARNING no model scale passed. Assuming scale='{scale}'.")
+        depth, width, max_channels = scales[scale]
+    if act:
+        Conv.default_act = eval(act)   # noqa: S307 - same contract as the reference (tasks.py:620-621), e.g. 'nn.SiLU()'
+    ch = [ch]
+    red = [1]       # spatial reduction of each layer output relative to the input image
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, mname, args) in enumerate(d['backbone'] + d['head']):
+        if mname not in REGISTRY:
+            raise KeyError(mname)   # unknown module name -> KeyError like globals()[m] in the reference
+        m = REGISTRY[mname]
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = nc if a == 'nc' else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        r_in = red[f] if isinstance(f, int) else None
+        if m in (Conv, DWConv, Bottleneck, SPPF, C2f, MSPA_C2f):
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m in (C2f, MSPA_C2f):
+                args.insert(2, n)
+                n = 1
+            r_out = r_in * (args[3] if m in (Conv, DWConv) and len(args) > 3 else 1)
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+            r_out = red[f[0]]
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+            r_out = red[f[0]]
+        elif m is SimFusion_4in:
+            c2 = sum(ch[x] for x in f)
+            r_out = red[f[2]]
+        elif m is SimFusion_3in:
+            c2 = args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [[ch[f_] for f_ in f], c2]
+            r_out = red[f[1]]
+        elif m is IFM:
+            c1 = ch[f]
+            c2 = sum(args[0])
+            args = [c1, *args]
+            r_out = r_in
+        elif m is InjectionMultiSum_Auto_pool:
+            c1 = ch[f[0]]
+            c2 = args[0]
+            args = [c1, *args]
+            r_out = red[f[0]]
+        elif m is Upsample:
+            c2 = ch[f]
+            r_out = r_in / args[1]
+        else:
+            c2 = ch[f]
+            r_out = r_in
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = f'{m.__module__}.{m.__name__}'
+        m.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, t
+        if verbose:
+            print(f'{i:>3}{str(f):>20}{n_:>3}{m.np:10.0f}  {t:<45}{str(args):<30}')
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch, red = [], []
+        ch.append(c2)
+        red.append(r_out)
+    return nn.Sequential(*layers), sorted(save), red
+
+
+def guess_model_scale(model_path):
+    """Scale letter from a file stem such as 'yolov8n' / 'mspa_c2f_gd_yolov8s' (tasks.py:720-735)."""
+    with contextlib.suppress(AttributeError):
+        return re.search(r'yolov\d+([nslmx])', Path(model_path).stem).group(1)
+    return ''
+
+
+def yaml_model_load(path):
+    """Load a model YAML in the reference's schema; '...yolov8n.yaml' resolves to '...yolov8.yaml' + scale n (tasks.py:702-717).
+    Names of the built-in graphs (mgdt_yolo_amd.models.CONFIGS) resolve without a file."""
+    import yaml
+    from ..models import CONFIGS, get_config
+    path = Path(path)
+    scale = guess_model_scale(path)
+    unified = Path(re.sub(r'(\d+)([nslmx])(.+)?$', r'\1\3', str(path)))
+    for cand in (unified, path):
+        if cand.is_file():
+            with open(cand, errors='ignore', encoding='utf-8') as f:
+                d = yaml.safe_load(f)
+            d['scale'] = scale
+            d['yaml_file'] = str(path)
+            return d
+    if unified.stem in CONFIGS:
+        d = get_config(unified.stem, scale or 'n')
+        d['scale'] = scale
+        d['yaml_file'] = str(path)
+        return d
+    raise FileNotFoundError(f"'{path}' does not exist")

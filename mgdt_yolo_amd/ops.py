@@ -1,0 +1,217 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mgdt.h).  PyTorch is plumbing here: device memory,
+the current HIP stream, nn.Parameter containers.  Every compute step goes through libmgdt_hip.so.
+
+Activations are torch tensors shaped (B, C, H, W) in channels_last memory format (NHWC in memory); channel
+slices `t[:, a:b]` are passed as strided views - the reference's chunk()/split()/cat() never copy here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, View  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dtype_code(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise RuntimeError(f'mgdt_yolo_amd computes in float32 or bfloat16, not {dt}') from None
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('mgdt_yolo_amd runs on MI355X (HIP) only: got a CPU tensor and there is no CPU/PyTorch fallback')
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def view(t):
+    """(B,C,H,W) tensor of any strides -> mgdt_view (NHWC-ordered sizes/strides)."""
+    _need_gpu(t)
+    b, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    return View(t.data_ptr(), b, h, w, c, sn, sh, sw, sc)
+
+
+def vp(t):
+    return C.byref(view(t)) if t is not None else None
+
+
+def ptr(t):
+    if t is None:
+        return None
+    _need_gpu(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def new_act(b, c, h, w, dtype, device):
+    """NHWC activation buffer presented with NCHW shape semantics."""
+    return torch.empty((b, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def is_nhwc(t):
+    return t.stride(1) == 1
+
+
+# ------------------------------------------------------------------ conv
+class PackedConv:
+    """Caller-owned packed weights of one convolution (BN folded) for one compute dtype."""
+    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups')
+
+    def __init__(self, weight, conv_bias, bn, k, dtype, direct=False, groups=1):
+        """weight: (cout, cin/groups, k, k) fp32 cuda; bn: None or (gamma, beta, mean, var, eps)."""
+        lib = L.lib()
+        weight = weight.detach().float().contiguous()
+        _need_gpu(weight)
+        cout, cin_g = weight.shape[0], weight.shape[1]
+        dev = weight.device
+        g, b, mu, var, eps = (None, None, None, None, 0.0) if bn is None else bn
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        g, b, mu, var, cb = f(g), f(b), f(mu), f(var), f(conv_bias)
+        self.k, self.cin, self.cout, self.dtype, self.direct, self.groups = k, cin_g * groups, cout, dtype, direct, groups
+        if direct:
+            self.w = torch.empty(k * k * cin_g * cout, dtype=torch.float32, device=dev)
+            self.bias = torch.empty(cout, dtype=torch.float32, device=dev)
+            L.check(lib.mgdt_conv_pack_direct(ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k,
+                                              ptr(self.w), ptr(self.bias), stream()), 'conv_pack_direct')
+        else:
+            code = dtype_code(dtype)
+            nbytes = lib.mgdt_conv_packed_bytes(cin_g, cout, k, code)
+            self.w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.bias = torch.empty((cout + 15) // 16 * 16, dtype=torch.float32, device=dev)
+            L.check(lib.mgdt_conv_pack(ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k, code,
+                                       ptr(self.w), ptr(self.bias), stream()), 'conv_pack')
+
+
+def conv_can_mfma(x, cin, cout, k, s, groups, dtype):
+    pe = 8 if dtype == torch.bfloat16 else 4
+    return (groups == 1 and k in (1, 3) and s in (1, 2) and cin % pe == 0 and cout % 4 == 0 and x.dtype == dtype
+            and is_nhwc(x) and x.stride(3) % pe == 0 and x.stride(2) % pe == 0 and x.stride(0) % pe == 0
+            and x.data_ptr() % 16 == 0)
+
+
+def conv_out_hw(h, w, k, s):
+    p = k // 2
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+def conv2d(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=None, in_shift=None):
+    """Fused conv (see mgdt_conv2d_fwd).  Returns `out` (allocated NHWC when None)."""
+    _need_gpu(x)
+    b, _, h, w = x.shape
+    ho, wo = conv_out_hw(h, w, pk.k, stride)
+    if out is None:
+        out = new_act(b, pk.cout, ho, wo, pk.dtype, x.device)
+    lib = L.lib()
+    if pk.direct:
+        if x2 is not None or r1 is not None or r2 is not None or in_scale is not None or in_shift is not None:
+            raise RuntimeError('direct convolution path has no fused extras')
+        L.check(lib.mgdt_conv2d_direct_fwd(vp(x), dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
+                                           vp(out), dtype_code(out.dtype), stream()), 'conv2d_direct_fwd')
+    else:
+        L.check(lib.mgdt_conv2d_fwd(vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), pk.k, stride, act,
+                                    vp(r1), vp(r2), vp(out), dtype_code(pk.dtype), stream()), 'conv2d_fwd')
+    return out
+
+
+# ------------------------------------------------------------------ MSPA attention
+def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
+    """softmax_over_groups(SPR(x_group)) -> attn fp32 [B, C]."""
+    b, c, h, w = x.shape
+    lib = L.lib()
+    part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
+    L.check(lib.mgdt_spr_pool_fwd(vp(x), ptr(part), dtype_code(x.dtype), stream()), 'spr_pool_fwd')
+    attn = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    L.check(lib.mgdt_spr_attn_fwd(ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn),
+                                  stream()), 'spr_attn_fwd')
+    return attn
+
+
+def scale_channels(x, attn, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().mgdt_scale_channels_fwd(vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream()), 'scale_channels_fwd')
+    return out
+
+
+# ------------------------------------------------------------------ pools / resamplers
+def sppf_pools(x, y1, y2, y3):
+    L.check(L.lib().mgdt_sppf_pool_fwd(vp(x), vp(y1), vp(y2), vp(y3), dtype_code(x.dtype), stream()), 'sppf_pool_fwd')
+
+
+def adaptive_avgpool(x, out):
+    L.check(L.lib().mgdt_adaptive_avgpool_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'adaptive_avgpool_fwd')
+    return out
+
+
+def bilinear(x, out):
+    L.check(L.lib().mgdt_bilinear_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'bilinear_fwd')
+    return out
+
+
+def nearest(x, out):
+    L.check(L.lib().mgdt_nearest_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'nearest_fwd')
+    return out
+
+
+def copy(x, out):
+    """Strided copy with cast (channel concat, NCHW<->NHWC, fp32<->bf16)."""
+    L.check(L.lib().mgdt_copy_fwd(vp(x), dtype_code(x.dtype), vp(out), dtype_code(out.dtype), stream()), 'copy_fwd')
+    return out
+
+
+# ------------------------------------------------------------------ ConvNeXtV2 pieces, Injection, Detect
+def dwconv7_ln(x, dw_w49c, dw_b, ln_w, ln_b, eps, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().mgdt_dwconv7_ln_fwd(vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), eps, vp(out), dtype_code(x.dtype),
+                                        stream()), 'dwconv7_ln_fwd')
+    return out
+
+
+def grn_scale(t, gamma):
+    """scale[n,c] = gamma[c]*Nx[n,c] + 1 (fp32) for the GRN-folded pwconv2."""
+    b, c = t.shape[:2]
+    ws = torch.empty(b, c, dtype=torch.float32, device=t.device)
+    sc = torch.empty(b, c, dtype=torch.float32, device=t.device)
+    L.check(L.lib().mgdt_grn_stats_fwd(vp(t), ptr(gamma), ptr(ws), ptr(sc), dtype_code(t.dtype), stream()), 'grn_stats_fwd')
+    return sc
+
+
+def inject(local, ga, gf, out=None):
+    out = torch.empty_like(local) if out is None else out
+    L.check(L.lib().mgdt_inject_fwd(vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream()), 'inject_fwd')
+    return out
+
+
+def detect_decode(feat, reg_max, nc, stride, a_off, y):
+    """feat (B,no,H,W) NHWC -> y[B, 4+nc, A_total] fp32 at anchor offset a_off."""
+    L.check(L.lib().mgdt_detect_decode_fwd(vp(feat), reg_max, nc, float(stride), a_off, y.shape[2], ptr(y), dtype_code(feat.dtype),
+                                           stream()), 'detect_decode_fwd')
+
+
+# ------------------------------------------------------------------ NMS
+def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, max_nms, max_wh):
+    """pred (B, 4+nc, A) fp32 cuda contiguous -> (out [B,max_det,6], kept_anchor [B,max_det] int32, counts [B] int32)."""
+    _need_gpu(pred)
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        raise RuntimeError('nms: prediction must be a contiguous float32 tensor')
+    b, ch, a = pred.shape
+    nc = ch - 4
+    lib = L.lib()
+    ml = 1 if (multi_label and nc > 1) else 0
+    ws_bytes = lib.mgdt_nms_workspace_bytes(b, nc, a, ml, max_nms)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=pred.device)
+    out = torch.zeros(b, max_det, 6, dtype=torch.float32, device=pred.device)
+    kept = torch.zeros(b, max_det, dtype=torch.int32, device=pred.device)
+    counts = torch.zeros(b, dtype=torch.int32, device=pred.device)
+    cls_t = None
+    if classes is not None:
+        cls_t = torch.as_tensor(list(classes), dtype=torch.int32).to(pred.device)
+    L.check(lib.mgdt_nms_fwd(ptr(pred), b, nc, a, float(conf_thres), float(iou_thres), ptr(cls_t), 0 if cls_t is None else cls_t.numel(),
+                             int(bool(agnostic)), ml, max_det, max_nms, float(max_wh), ptr(out), ptr(kept), ptr(counts), ptr(ws),
+                             ws_bytes, stream()), 'nms_fwd')
+    return out, kept, counts

@@ -1,0 +1,197 @@
+"""Generate tests/golden/*.npz from the reference's own Python modules (BUILD CONTAINER ONLY).
+
+    python tests/golden/gen_golden.py
+
+Needs /root/reference (read-only) - see ref_import.py for the import recipe.  The outputs are data
+(inputs are re-creatable from seeds via mgdt_yolo_amd.seeding; expected outputs come from running
+the reference on CPU, fp32).  The GPU box never runs this file.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_import  # noqa: E402
+from mgdt_yolo_amd.seeding import seed_state_dict_, seeded_images, seeded_labels, seeded_tensor  # noqa: E402
+from oracle import nms as onms  # noqa: E402  (only to stand in for the absent torchvision.ops.nms)
+from inputs import (ASSIGNER_CASES, ASSIGNER_SHAPE, E2E_MODELS, E2E_SHAPES, IMG_SEED, LOSS_CASES, LOSS_SHAPE,  # noqa: E402
+                    MODULE_CASES, MODULE_SEED, NMS_CASES, assigner_inputs, loss_inputs, module_inputs)
+
+torch.set_num_threads(8)
+ns = ref_import.load()
+REFY = '/root/reference/models/v8/'
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def sample(t, n=2048):
+    f = t.detach().reshape(-1).double()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].float().numpy(), np.array([f.sum().item(), f.abs().sum().item()], np.float64)
+
+
+def build(yaml_name, nc=80, seed=0):
+    m = ns.tasks.DetectionModel(REFY + yaml_name, nc=nc, verbose=False)
+    seed_state_dict_(m, seed)
+    m.args = types.SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    return m.eval()
+
+
+# ------------------------------------------------------------------ end-to-end forward fixtures
+def e2e(tag, yaml_name, shapes):
+    m = build(yaml_name)
+    arrs = {'stride': m.stride.numpy()}
+    for (b, h, w) in shapes:
+        x = seeded_images(b, h, w, seed=IMG_SEED)
+        layers = []
+        hooks = [l.register_forward_hook(lambda mod, i, o, L=layers: L.append(o)) for l in m.model]
+        with torch.no_grad():
+            y, feats = m(x)
+        for hk in hooks:
+            hk.remove()
+        key = f'{b}x{h}x{w}'
+        if h * w <= 160 * 160:
+            arrs[f'y_{key}'] = y.numpy()
+            for i, f in enumerate(feats):
+                arrs[f'feat{i}_{key}'] = f.numpy()
+        else:
+            arrs[f'ysub_{key}'] = y[:, :, ::25].numpy()
+        for i, o in enumerate(layers[:-1]):
+            s, st = sample(o)
+            arrs[f'L{i}_s_{key}'], arrs[f'L{i}_st_{key}'] = s, st
+    # fused model (AutoBackend path, autobackend.py:94) on the first shape
+    b, h, w = shapes[0]
+    mf = build(yaml_name).fuse(verbose=False)
+    with torch.no_grad():
+        yf, _ = mf(seeded_images(b, h, w, seed=IMG_SEED))
+    arrs[f'yfused_{b}x{h}x{w}'] = yf.numpy()
+    save(f'e2e_{tag}', **arrs)
+    return m
+
+
+# ------------------------------------------------------------------ per-module fixtures
+def modules():
+    import ultralytics.nn.modules.block as RB
+    arrs = {}
+    for name, (cls, args, _) in MODULE_CASES.items():
+        args = tuple(torch.nn.ReLU() if a == 'relu' else a for a in args)
+        ctor = getattr(ns.modules, cls, None) or getattr(RB, cls)
+        mod = seed_state_dict_(ctor(*args), MODULE_SEED).eval()
+        for sub in mod.modules():
+            if isinstance(sub, torch.nn.BatchNorm2d):
+                sub.eps = 1e-3   # what initialize_weights does inside DetectionModel (torch_utils.py:254)
+        xs = module_inputs(name)
+        with torch.no_grad():
+            arrs[name] = mod(xs[0] if len(xs) == 1 else xs).numpy()
+    save('modules', **arrs)
+
+
+# ------------------------------------------------------------------ CIoU / box_iou
+def boxes():
+    r = np.random.default_rng(5)
+    c1, c2 = r.uniform(50, 500, (512, 2)), r.uniform(50, 500, (512, 2))
+    c2[:256] = c1[:256] + r.normal(0, 12, (256, 2))
+    w1, w2 = r.uniform(4, 200, (512, 2)), r.uniform(4, 200, (512, 2))
+    b1 = np.concatenate([c1 - w1 / 2, c1 + w1 / 2], 1).astype(np.float32)
+    b2 = np.concatenate([c2 - w2 / 2, c2 + w2 / 2], 1).astype(np.float32)
+    t1, t2 = torch.from_numpy(b1), torch.from_numpy(b2)
+    ciou = ns.metrics.bbox_iou(t1, t2, xywh=False, CIoU=True)
+    iou = ns.metrics.box_iou(t1[:64], t2[:96])
+    save('boxes', b1=b1, b2=b2, ciou=ciou.numpy(), box_iou=iou.numpy())
+
+
+# ------------------------------------------------------------------ assigner + loss
+def assigner():
+    from oracle.loss import dense_targets
+    arrs = {}
+    B, nc, hw = ASSIGNER_SHAPE['B'], ASSIGNER_SHAPE['nc'], ASSIGNER_SHAPE['hw']
+    for seed, calls in ASSIGNER_CASES:
+        lab, pd_scores, pd_bboxes, anc = assigner_inputs(B, nc, hw, seed)
+        imgsz = torch.tensor([hw[0] * 8, hw[1] * 8], dtype=torch.float32)
+        tg = dense_targets(lab['batch_idx'], lab['cls'], lab['bboxes'], B, imgsz[[1, 0, 1, 0]])
+        gl, gb = tg.split((1, 4), 2)
+        mg = gb.sum(2, keepdim=True).gt_(0)
+        a = ns.tal.HeuristicPositiveSampleAssigner_v1(num_classes=nc, alpha=0.5, beta=8.0, iou_threshold=0.4)
+        tl, tb, ts, fg, gi = a(pd_scores, pd_bboxes, anc, gl, gb, mg, calls)
+        k = f's{seed}'
+        arrs[k + '_calls'] = calls
+        arrs[k + '_fg'] = fg.numpy()
+        arrs[k + '_gt_idx'] = gi.numpy().astype(np.int32)
+        arrs[k + '_labels'] = tl.numpy().astype(np.int32)
+        arrs[k + '_scores'] = ts.numpy()
+        arrs[k + '_bboxes'] = tb.numpy()
+        print('assigner', k, 'positives', int(fg.sum()))
+    save('assigner', **arrs)
+
+
+def loss():
+    arrs = {}
+    B, nc, R, hw = (LOSS_SHAPE[k] for k in ('B', 'nc', 'R', 'hw'))
+    no = 4 * R + nc
+    for seed, calls in LOSS_CASES:
+        feats, lab = loss_inputs(seed, B, nc, R, hw)
+        head = types.SimpleNamespace(stride=torch.tensor([8.0]), nc=nc, no=no, reg_max=R)
+        model = types.SimpleNamespace(args=types.SimpleNamespace(box=7.5, cls=0.5, dfl=1.5), model=[head],
+                                      parameters=lambda: iter([torch.zeros(1)]))
+        crit = ns.loss.v8DetectionLoss(model)
+        crit.epoch = calls
+        f = feats.clone().requires_grad_(True)
+        total, items = crit([f], lab)
+        total.backward()
+        k = f's{seed}'
+        arrs[k + '_calls'] = calls
+        arrs[k + '_total'] = total.detach().numpy()
+        arrs[k + '_items'] = items.numpy()
+        arrs[k + '_grad'] = f.grad.numpy()
+        print('loss', k, float(total), items.tolist())
+    save('loss', **arrs)
+
+
+# ------------------------------------------------------------------ NMS (stages around the absent torchvision op)
+def nms(models):
+    import torchvision  # the stand-in module from ref_import
+
+    def nms_standin(boxes, scores, thr):
+        assert bool((scores[:-1] >= scores[1:]).all()), 'reference hands nms() descending scores'
+        return torch.from_numpy(onms.greedy_nms(boxes.numpy(), thr))
+
+    torchvision.ops.nms = nms_standin
+    arrs = {}
+    for tag, m in models.items():
+        with torch.no_grad():
+            y, _ = m(seeded_images(2, 160, 160, seed=IMG_SEED))
+        for cname, kw in NMS_CASES:
+            out = ns.ops.non_max_suppression(y.clone(), max_time_img=1e9, **kw)
+            for i, o in enumerate(out):
+                arrs[f'{tag}_{cname}_{i}'] = o.numpy()
+            print('nms', tag, cname, [int(o.shape[0]) for o in out])
+    save('nms', **arrs)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms']
+    models = {}
+    if 'e2e' in what or 'nms' in what:
+        for tag, yname in E2E_MODELS.items():
+            models[tag] = e2e(tag, yname + '.yaml', E2E_SHAPES) if 'e2e' in what else build(yname + '.yaml')
+    if 'modules' in what:
+        modules()
+    if 'boxes' in what:
+        boxes()
+    if 'assigner' in what:
+        assigner()
+    if 'loss' in what:
+        loss()
+    if 'nms' in what:
+        nms(models)

@@ -1,0 +1,185 @@
+"""The CPU oracle against the fixtures generated from the reference (tests/golden/gen_golden.py).
+
+Runs without a GPU.  This is what "pins" the oracle: every restated function reproduces what the
+reference's own Python computed on the same seeded inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import inputs as GI
+from mgdt_yolo_amd.models import get_config
+from mgdt_yolo_amd.seeding import seeded_images, seeded_tensor
+from oracle import boxes as OB
+from oracle import layers as OL
+from oracle import loss as OLoss
+from oracle import nms as ON
+from oracle import tal as OT
+
+torch.set_num_threads(8)
+
+
+def oracle_state_dict(shapes, seed):
+    """state_dict with the reference's names, filled by the shared seeding rule."""
+    sd = {}
+    for k, shp in shapes.items():
+        v = seeded_tensor(k, shp, seed)
+        if v is None:
+            v = torch.arange(shp[1], dtype=torch.float32).view(shp) if k.endswith('dfl.conv.weight') else torch.zeros(shp)
+        sd[k] = v
+    return sd
+
+
+def model_shapes(name, scale='n', nc=80):
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    m = DetectionModel(get_config(name, scale, nc), verbose=False)
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}, m.stride.tolist()
+
+
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_e2e_forward_matches_reference(golden, tag):
+    g = golden('e2e_' + tag)
+    name = GI.E2E_MODELS[tag]
+    shapes, strides = model_shapes(name)
+    assert strides == g['stride'].tolist()
+    sd = oracle_state_dict(shapes, 0)
+    cfg = get_config(name, 'n')
+    for (b, h, w) in GI.E2E_SHAPES:
+        key = f'{b}x{h}x{w}'
+        x = seeded_images(b, h, w, seed=GI.IMG_SEED)
+        with torch.no_grad():
+            (y, feats), layers = OL.model_forward(cfg, sd, x, strides, return_layers=True)
+        if f'y_{key}' in g:
+            np.testing.assert_allclose(y.numpy()[:, :4], g[f'y_{key}'][:, :4], atol=5e-4, rtol=0)   # px
+            np.testing.assert_allclose(y.numpy()[:, 4:], g[f'y_{key}'][:, 4:], atol=2e-5, rtol=0)   # conf
+            for i, f in enumerate(feats):
+                np.testing.assert_allclose(f.numpy(), g[f'feat{i}_{key}'], atol=1e-4, rtol=1e-5)
+        else:
+            np.testing.assert_allclose(y.numpy()[:, :4, ::25], g[f'ysub_{key}'][:, :4], atol=5e-4, rtol=0)
+            np.testing.assert_allclose(y.numpy()[:, 4:, ::25], g[f"ysub_{key}"][:, 4:], atol=2e-5, rtol=0)
+        for i, o in enumerate(layers[:-1]):
+            f = o.reshape(-1).double()
+            step = max(1, f.numel() // 2048)
+            np.testing.assert_allclose(f[::step][:2048].float().numpy(), g[f'L{i}_s_{key}'], atol=2e-4, rtol=1e-4)
+    # BN-folded path (fuse_conv_and_bn) agrees with the reference's fused model
+    b, h, w = GI.E2E_SHAPES[0]
+    with torch.no_grad():
+        yf, _ = OL.model_forward(cfg, sd, seeded_images(b, h, w, seed=GI.IMG_SEED), strides, fused=True)
+    np.testing.assert_allclose(yf.numpy()[:, :4], g[f'yfused_{b}x{h}x{w}'][:, :4], atol=2e-4, rtol=0)
+
+
+def _oracle_module(name, cls, args, sd, xs):
+    x = xs[0] if len(xs) == 1 else xs
+    if cls == 'Conv':
+        act = 'silu' if len(args) < 8 else {'relu': 'relu', False: 'none'}[args[7]]
+        return OL.conv(x, sd, 'm', s=args[3], act=act)
+    if cls == 'Bottleneck':
+        return OL.bottleneck(x, sd, 'm', args[2])
+    if cls == 'C2f':
+        return OL.c2f(x, sd, 'm', args[2], args[3])
+    if cls == 'MSPA_C2f':
+        return OL.mspa_c2f(x, sd, 'm', args[2], args[3])
+    if cls == 'SPPF':
+        return OL.sppf(x, sd, 'm')
+    if cls == 'SimFusion_4in':
+        return OL.simfusion_4in(x)
+    if cls == 'SimFusion_3in':
+        return OL.simfusion_3in(x, sd, 'm')
+    if cls == 'IFM':
+        return OL.ifm(x, sd, 'm')
+    if cls == 'InjectionMultiSum_Auto_pool':
+        return OL.inject(x, sd, 'm', args[2], args[3])
+    raise KeyError(cls)
+
+
+@pytest.mark.parametrize('name', list(GI.MODULE_CASES))
+def test_module_matches_reference(golden, name):
+    import mgdt_yolo_amd.nn.modules as M
+    g = golden('modules')
+    cls, args, _ = GI.MODULE_CASES[name]
+    ctor_args = tuple(torch.nn.ReLU() if a == 'relu' else a for a in args)
+    shapes = {'m.' + k: tuple(v.shape) for k, v in getattr(M, cls)(*ctor_args).state_dict().items()}
+    # seeding is keyed on the name the reference module used ('' prefix), so re-key
+    sd = {}
+    for k, shp in shapes.items():
+        v = seeded_tensor(k[2:], shp, GI.MODULE_SEED)
+        sd[k] = v if v is not None else torch.zeros(shp)
+    with torch.no_grad():
+        y = _oracle_module(name, cls, args, sd, GI.module_inputs(name))
+    np.testing.assert_allclose(y.numpy(), g[name], atol=3e-5, rtol=1e-5)
+
+
+def test_ciou_and_box_iou(golden):
+    g = golden('boxes')
+    b1, b2 = torch.from_numpy(g['b1']), torch.from_numpy(g['b2'])
+    np.testing.assert_allclose(OB.ciou_xyxy(b1, b2).numpy(), g['ciou'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(OB.box_iou(b1[:64], b2[:96]).numpy(), g['box_iou'], atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize('seed,calls', GI.ASSIGNER_CASES)
+def test_assigner_matches_reference(golden, seed, calls):
+    g = golden('assigner')
+    B, nc, hw = (GI.ASSIGNER_SHAPE[k] for k in ('B', 'nc', 'hw'))
+    lab, pd_scores, pd_bboxes, anc = GI.assigner_inputs(B, nc, hw, seed)
+    imgsz = torch.tensor([hw[0] * 8, hw[1] * 8], dtype=torch.float32)
+    tg = OLoss.dense_targets(lab['batch_idx'], lab['cls'], lab['bboxes'], B, imgsz[[1, 0, 1, 0]])
+    gl, gb = tg.split((1, 4), 2)
+    mg = (gb.sum(2, keepdim=True) > 0).float()
+    tl, tb, ts, fg, gi = OT.assign(pd_scores, pd_bboxes, anc, gl, gb, mg, calls, nc)
+    k = f's{seed}'
+    assert int(g[k + '_calls']) == calls
+    assert np.array_equal(fg.numpy(), g[k + '_fg'])                      # integer outputs: bit exact
+    assert np.array_equal(gi.numpy(), g[k + '_gt_idx'])
+    assert np.array_equal(tl.numpy(), g[k + '_labels'])
+    np.testing.assert_allclose(tb.numpy(), g[k + '_bboxes'], atol=0, rtol=0)
+    np.testing.assert_allclose(ts.numpy(), g[k + '_scores'], atol=1e-6, rtol=1e-5)
+
+
+def test_assigner_empty_labels_is_all_background():
+    """Reference crashes here (tal.py:102-108); the build defines upstream behaviour."""
+    out = OT.assign(torch.rand(2, 30, 4), torch.rand(2, 30, 4), torch.rand(30, 2), torch.zeros(2, 0, 1),
+                    torch.zeros(2, 0, 4), torch.zeros(2, 0, 1), 0, 4)
+    assert out[3].sum() == 0 and (out[0] == 4).all() and out[2].sum() == 0
+
+
+@pytest.mark.parametrize('seed,calls', GI.LOSS_CASES)
+def test_detection_loss_matches_reference(golden, seed, calls):
+    g = golden('loss')
+    B, nc, R, hw = (GI.LOSS_SHAPE[k] for k in ('B', 'nc', 'R', 'hw'))
+    feats, lab = GI.loss_inputs(seed, B, nc, R, hw)
+    f = feats.clone().requires_grad_(True)
+    total, items, _ = OLoss.detection_loss([f], lab, [8.0], R, nc, call_count=calls)
+    total.backward()
+    k = f's{seed}'
+    np.testing.assert_allclose(total.item(), g[k + '_total'], rtol=2e-6)
+    np.testing.assert_allclose(items.numpy(), g[k + '_items'], rtol=2e-6)
+    np.testing.assert_allclose(f.grad.numpy(), g[k + '_grad'], atol=2e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_nms_stages_match_reference(golden, tag):
+    """Everything in non_max_suppression around the (absent, unpinned) torchvision.ops.nms call."""
+    g, y = golden('nms'), golden('e2e_' + tag)['y_2x160x160']
+    for cname, kw in GI.NMS_CASES:
+        out = ON.non_max_suppression(y, **kw)
+        for i, o in enumerate(out):
+            ref = g[f'{tag}_{cname}_{i}']
+            assert o.shape == ref.shape, (cname, i, o.shape, ref.shape)
+            assert np.array_equal(o, ref), (cname, i)
+
+
+def test_greedy_nms_properties():
+    """torchvision.ops.nms is unpinned: check the published semantics through its invariants."""
+    r = np.random.default_rng(0)
+    c = r.uniform(0, 100, (400, 2)); wh = r.uniform(5, 40, (400, 2))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    keep = ON.greedy_nms(b, 0.5)
+    assert keep[0] == 0 and np.all(np.diff(keep) > 0)
+    iou = OB.box_iou(torch.from_numpy(b[keep]), torch.from_numpy(b[keep]), eps=0).numpy()
+    assert (iou[np.triu_indices(len(keep), 1)] <= 0.5 + 1e-6).all()          # survivors do not overlap > thr
+    dropped = np.setdiff1d(np.arange(400), keep)
+    iou_d = OB.box_iou(torch.from_numpy(b[dropped]), torch.from_numpy(b[keep]), eps=0).numpy()
+    for j, d in enumerate(dropped):                                             # each dropped box has an earlier keeper
+        assert (iou_d[j][keep < d] > 0.5 - 1e-6).any()
+    assert np.array_equal(ON.greedy_nms(b[keep], 0.5), np.arange(len(keep)))   # idempotent
+    assert len(ON.greedy_nms(np.zeros((0, 4), np.float32), 0.5)) == 0
