@@ -1,0 +1,197 @@
+"""Headline benchmark: images/sec @640x640, batch 32 per GPU, MSPA-C2f + GD-neck YOLOv8n (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one resident batch: detection forward (all layers, HIP kernels through the
+C ABI) + Detect decode + batched NMS (predict settings conf 0.25 / iou 0.7), replayed from a hipGraph.
+Inputs (fp32 NCHW images) are already in HBM when the timed region starts.  Inference shards over the batch with
+no collective: N ranks = N replicas with disjoint batches ("weak" scaling); the only collective is the MAX of
+the per-rank times.  Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the CPU oracle - a port of the reference's path - timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--imgsz', type=int, default=640)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--model', default='mspa_c2f_gd_yolov8')
+    ap.add_argument('--scale', default='n')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, model, args):
+    """The oracle (CPU port of the reference path: forward with folded BN + NMS) on a bounded sample."""
+    from mgdt_yolo_amd.seeding import seeded_images
+    from oracle import layers as OL
+    from oracle import nms as ON
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    # a 1-GPU box is granted a 16-core CPU share whatever the affinity mask says: more threads only thrash
+    cores = int(os.environ.get('MGDT_CPU_THREADS', min(cores, 16)))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    x = seeded_images(args.cpu_images, args.imgsz, args.imgsz, seed=0)
+    strides = model.stride.tolist()
+
+    def once():
+        with torch.no_grad():
+            y, _ = OL.model_forward(cfg, sd, x, strides, fused=True)
+        ON.non_max_suppression(y.numpy(), conf_thres=0.25, iou_thres=0.7)
+    once()                      # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 10 and reps < 20):
+        once()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(args.cpu_images * reps / dt, 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} x batch {args.cpu_images} @ {args.imgsz}x{args.imgsz}, torch-CPU fp32 oracle forward (BN folded) + numpy NMS'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.models import get_config
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seed_state_dict_, seeded_images
+    from mgdt_yolo_amd.yolo.utils.ops import non_max_suppression  # noqa: F401  (the user-facing form; the graph uses ops.nms)
+
+    cfg = get_config(args.model, args.scale, 80)
+    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).eval().to(dev).set_compute_dtype(tdt)
+    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=100 + rank).to(dev)     # resident in HBM
+
+    def step():
+        y, _ = model(x)
+        return ops.nms(y, 0.25, 0.7, None, False, False, 300, 30000, 7680)
+
+    with torch.no_grad():
+        out = step()                       # packs the weights, allocates
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    out = step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+        run = graph.replay if graph is not None else step
+
+        for _ in range(args.warmup):
+            run()
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        elapsed = t1 - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        n_det = int(out[2].sum().item())
+
+        # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
+        roof = None
+        if rank == 0:
+            with ops.profile() as prof:
+                for _ in range(3):
+                    step()
+            agg = {}
+            for name, meta, ms in prof.rows:
+                key = (name, meta['shape'] if meta else None)
+                a = agg.setdefault(key, [0.0, 0, meta])
+                a[0] += ms
+                a[1] += 1
+            total_ms = sum(v[0] for v in agg.values()) / 3
+            per_name = {}
+            for (name, _), v in agg.items():
+                per_name[name] = per_name.get(name, 0.0) + v[0] / 3
+            conv = [(k, v) for k, v in agg.items() if v[2] is not None]
+            (name, shape), (ms, cnt, meta) = max(conv, key=lambda kv: kv[1][0])
+            avg_s = ms / cnt * 1e-3
+            ai = meta['flops'] / meta['bytes']
+            ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai >= ridge:
+                ach = meta['flops'] / avg_s / 1e12
+                roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                        'frac': round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+            else:
+                ach = meta['bytes'] / avg_s / 1e9
+                roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
+            roof.update({'traffic': None, 'kernel': f'conv_igemm_kernel {name}', 'shape_b_cin_h_w_cout_k_s': list(shape),
+                         'avg_us': round(avg_s * 1e6, 2), 'launches_per_step': cnt // 3, 'flops_per_launch': meta['flops'],
+                         'bytes_per_launch': meta['bytes'], 'arith_intensity': round(ai, 1),
+                         'eager_ms_per_step_by_op': {k: round(v, 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1])},
+                         'eager_ms_per_step': round(total_ms, 3)})
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        line = {'metric': 'images/sec @640x640 bs=32 per GPU, detection forward + NMS', 'value': round(value, 1), 'unit': 'images/sec',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+                'config': {'workload': f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, '
+                                       f'batch {args.batch}/GPU: forward + decode + NMS(conf 0.25, iou 0.7), hipGraph replay' if graph is not None
+                           else f'{args.model}-{args.scale} {args.imgsz}x{args.imgsz} eager',
+                           'global_batch': world * args.batch, 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
+                           'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)'},
+                'roofline': roof}
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(cfg, model, args)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

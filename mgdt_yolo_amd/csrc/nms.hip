@@ -232,11 +232,11 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   long cand = multi_label ? (long)a * nc : a;
   g.cap_pow2 = next_pow2((int)std::min<long>(cand, max_nms));
   g.ws_per_image = g.cap_pow2 + (multi_label ? 0 : a);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+  static size_t attr_lds = 0;   // static LDS (histogram) + dynamic must stay <= 160 KiB: ask for what is needed only
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "nms: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+    attr_lds = lds;
   }
   nms_kernel<<<n, NMS_THREADS, lds, (hipStream_t)s>>>(g);
   MGDT_CHECK_LAUNCH("nms_fwd");

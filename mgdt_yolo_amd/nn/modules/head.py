@@ -63,15 +63,16 @@ class Detect(HipModule):
             x[i] = feat
         if self.training:
             return x
+        strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])  # host copy, no sync per call
         if self.dynamic or self.shape != shape:
             from ...yolo.utils.tal import make_anchors
-            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, self.stride, 0.5))
+            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, strides, 0.5))
             self.shape = shape
         a_total = sum(f.shape[2] * f.shape[3] for f in x)
         y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
         a_off = 0
         for i, f in enumerate(x):
-            ops.detect_decode(f, self.reg_max, self.nc, float(self.stride[i]), a_off, y)
+            ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
 

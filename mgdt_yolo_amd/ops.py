@@ -26,6 +26,41 @@ def _need_gpu(t):
         raise RuntimeError('mgdt_yolo_amd runs on MI355X (HIP) only: got a CPU tensor and there is no CPU/PyTorch fallback')
 
 
+_PROF = None   # list collecting (name, meta, start_event, end_event) while ops.profile() is active
+
+
+def _launch(name, symbol, *args, meta=None):
+    """Call one C-ABI entry point on the current stream; raise on a non-zero status."""
+    fn = getattr(L.lib(), symbol)
+    if _PROF is None:
+        L.check(fn(*args), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(fn(*args), name)
+    e1.record()
+    _PROF.append((name, meta or _META.pop(name, None), e0, e1))
+
+
+_META = {}
+
+
+class profile:
+    """with ops.profile() as p: ...  -> p.rows = [(name, meta, ms)] measured with HIP events on the launch stream."""
+
+    def __enter__(self):
+        global _PROF
+        _PROF = self._raw = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        _PROF = None
+        torch.cuda.synchronize()
+        self.rows = [(n, m, a.elapsed_time(b)) for n, m, a, b in self._raw]
+        return False
+
+
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -77,15 +112,15 @@ class PackedConv:
         if direct:
             self.w = torch.empty(k * k * cin_g * cout, dtype=torch.float32, device=dev)
             self.bias = torch.empty(cout, dtype=torch.float32, device=dev)
-            L.check(lib.mgdt_conv_pack_direct(ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k,
-                                              ptr(self.w), ptr(self.bias), stream()), 'conv_pack_direct')
+            _launch('conv_pack_direct', 'mgdt_conv_pack_direct', ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k,
+                                              ptr(self.w), ptr(self.bias), stream())
         else:
             code = dtype_code(dtype)
             nbytes = lib.mgdt_conv_packed_bytes(cin_g, cout, k, code)
             self.w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self.bias = torch.empty((cout + 15) // 16 * 16, dtype=torch.float32, device=dev)
-            L.check(lib.mgdt_conv_pack(ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k, code,
-                                       ptr(self.w), ptr(self.bias), stream()), 'conv_pack')
+            _launch('conv_pack', 'mgdt_conv_pack', ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k, code,
+                                       ptr(self.w), ptr(self.bias), stream())
 
 
 def conv_can_mfma(x, cin, cout, k, s, groups, dtype):
@@ -107,15 +142,19 @@ def conv2d(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=Non
     ho, wo = conv_out_hw(h, w, pk.k, stride)
     if out is None:
         out = new_act(b, pk.cout, ho, wo, pk.dtype, x.device)
-    lib = L.lib()
+    if _PROF is not None:
+        es = out.element_size()
+        _META['conv2d_direct_fwd' if pk.direct else 'conv2d_fwd'] = dict(
+            shape=(b, pk.cin, h, w, pk.cout, pk.k, stride), flops=2.0 * b * ho * wo * pk.cout * pk.cin // pk.groups * pk.k * pk.k,
+            bytes=float(b * h * w * pk.cin * x.element_size() + b * ho * wo * pk.cout * es + pk.w.numel() * pk.w.element_size()))
     if pk.direct:
         if x2 is not None or r1 is not None or r2 is not None or in_scale is not None or in_shift is not None:
             raise RuntimeError('direct convolution path has no fused extras')
-        L.check(lib.mgdt_conv2d_direct_fwd(vp(x), dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
-                                           vp(out), dtype_code(out.dtype), stream()), 'conv2d_direct_fwd')
+        _launch('conv2d_direct_fwd', 'mgdt_conv2d_direct_fwd', vp(x), dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
+                                           vp(out), dtype_code(out.dtype), stream())
     else:
-        L.check(lib.mgdt_conv2d_fwd(vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), pk.k, stride, act,
-                                    vp(r1), vp(r2), vp(out), dtype_code(pk.dtype), stream()), 'conv2d_fwd')
+        _launch('conv2d_fwd', 'mgdt_conv2d_fwd', vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), pk.k, stride, act,
+                                    vp(r1), vp(r2), vp(out), dtype_code(pk.dtype), stream())
     return out
 
 
@@ -125,50 +164,50 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     b, c, h, w = x.shape
     lib = L.lib()
     part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
-    L.check(lib.mgdt_spr_pool_fwd(vp(x), ptr(part), dtype_code(x.dtype), stream()), 'spr_pool_fwd')
+    _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
     attn = torch.empty(b, c, dtype=torch.float32, device=x.device)
-    L.check(lib.mgdt_spr_attn_fwd(ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn),
-                                  stream()), 'spr_attn_fwd')
+    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn),
+                                  stream())
     return attn
 
 
 def scale_channels(x, attn, out=None):
     out = torch.empty_like(x) if out is None else out
-    L.check(L.lib().mgdt_scale_channels_fwd(vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream()), 'scale_channels_fwd')
+    _launch('scale_channels_fwd', 'mgdt_scale_channels_fwd', vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 # ------------------------------------------------------------------ pools / resamplers
 def sppf_pools(x, y1, y2, y3):
-    L.check(L.lib().mgdt_sppf_pool_fwd(vp(x), vp(y1), vp(y2), vp(y3), dtype_code(x.dtype), stream()), 'sppf_pool_fwd')
+    _launch('sppf_pool_fwd', 'mgdt_sppf_pool_fwd', vp(x), vp(y1), vp(y2), vp(y3), dtype_code(x.dtype), stream())
 
 
 def adaptive_avgpool(x, out):
-    L.check(L.lib().mgdt_adaptive_avgpool_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'adaptive_avgpool_fwd')
+    _launch('adaptive_avgpool_fwd', 'mgdt_adaptive_avgpool_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def bilinear(x, out):
-    L.check(L.lib().mgdt_bilinear_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'bilinear_fwd')
+    _launch('bilinear_fwd', 'mgdt_bilinear_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def nearest(x, out):
-    L.check(L.lib().mgdt_nearest_fwd(vp(x), vp(out), dtype_code(x.dtype), stream()), 'nearest_fwd')
+    _launch('nearest_fwd', 'mgdt_nearest_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def copy(x, out):
     """Strided copy with cast (channel concat, NCHW<->NHWC, fp32<->bf16)."""
-    L.check(L.lib().mgdt_copy_fwd(vp(x), dtype_code(x.dtype), vp(out), dtype_code(out.dtype), stream()), 'copy_fwd')
+    _launch('copy_fwd', 'mgdt_copy_fwd', vp(x), dtype_code(x.dtype), vp(out), dtype_code(out.dtype), stream())
     return out
 
 
 # ------------------------------------------------------------------ ConvNeXtV2 pieces, Injection, Detect
 def dwconv7_ln(x, dw_w49c, dw_b, ln_w, ln_b, eps, out=None):
     out = torch.empty_like(x) if out is None else out
-    L.check(L.lib().mgdt_dwconv7_ln_fwd(vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), eps, vp(out), dtype_code(x.dtype),
-                                        stream()), 'dwconv7_ln_fwd')
+    _launch('dwconv7_ln_fwd', 'mgdt_dwconv7_ln_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), eps, vp(out), dtype_code(x.dtype),
+                                        stream())
     return out
 
 
@@ -177,20 +216,20 @@ def grn_scale(t, gamma):
     b, c = t.shape[:2]
     ws = torch.empty(b, c, dtype=torch.float32, device=t.device)
     sc = torch.empty(b, c, dtype=torch.float32, device=t.device)
-    L.check(L.lib().mgdt_grn_stats_fwd(vp(t), ptr(gamma), ptr(ws), ptr(sc), dtype_code(t.dtype), stream()), 'grn_stats_fwd')
+    _launch('grn_stats_fwd', 'mgdt_grn_stats_fwd', vp(t), ptr(gamma), ptr(ws), ptr(sc), dtype_code(t.dtype), stream())
     return sc
 
 
 def inject(local, ga, gf, out=None):
     out = torch.empty_like(local) if out is None else out
-    L.check(L.lib().mgdt_inject_fwd(vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream()), 'inject_fwd')
+    _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())
     return out
 
 
 def detect_decode(feat, reg_max, nc, stride, a_off, y):
     """feat (B,no,H,W) NHWC -> y[B, 4+nc, A_total] fp32 at anchor offset a_off."""
-    L.check(L.lib().mgdt_detect_decode_fwd(vp(feat), reg_max, nc, float(stride), a_off, y.shape[2], ptr(y), dtype_code(feat.dtype),
-                                           stream()), 'detect_decode_fwd')
+    _launch('detect_decode_fwd', 'mgdt_detect_decode_fwd', vp(feat), reg_max, nc, float(stride), a_off, y.shape[2], ptr(y), dtype_code(feat.dtype),
+                                           stream())
 
 
 # ------------------------------------------------------------------ NMS
@@ -211,7 +250,7 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, ma
     cls_t = None
     if classes is not None:
         cls_t = torch.as_tensor(list(classes), dtype=torch.int32).to(pred.device)
-    L.check(lib.mgdt_nms_fwd(ptr(pred), b, nc, a, float(conf_thres), float(iou_thres), ptr(cls_t), 0 if cls_t is None else cls_t.numel(),
+    _launch('nms_fwd', 'mgdt_nms_fwd', ptr(pred), b, nc, a, float(conf_thres), float(iou_thres), ptr(cls_t), 0 if cls_t is None else cls_t.numel(),
                              int(bool(agnostic)), ml, max_det, max_nms, float(max_wh), ptr(out), ptr(kept), ptr(counts), ptr(ws),
-                             ws_bytes, stream()), 'nms_fwd')
+                             ws_bytes, stream())
     return out, kept, counts

