@@ -73,16 +73,13 @@ def cpu_baseline(cfg, model, args):
 
 def main():
     args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    from mgdt_yolo_amd import parallel
+    rank, local, world = parallel.env_rank()
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        dist = parallel.init('nccl', dev)
 
     from mgdt_yolo_amd import ops
     from mgdt_yolo_amd.models import get_config
@@ -93,7 +90,7 @@ def main():
     cfg = get_config(args.model, args.scale, 80)
     tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).eval().to(dev).set_compute_dtype(tdt)
-    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=100 + rank).to(dev)     # resident in HBM
+    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100, rank)).to(dev)     # resident in HBM
 
     def step():
         y, _ = model(x)
@@ -131,11 +128,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier()
-        elapsed = t1 - t0
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
+        elapsed = parallel.max_over_ranks(t1 - t0, dev)
         n_det = int(out[2].sum().item())
 
         # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
@@ -174,7 +167,7 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        value = world * args.batch * args.steps / elapsed
+        value = parallel.aggregate_throughput(args.batch, args.steps, elapsed, world)
         line = {'metric': 'images/sec @640x640 bs=32 per GPU, detection forward + NMS', 'value': round(value, 1), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

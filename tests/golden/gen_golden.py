@@ -51,7 +51,8 @@ def build(yaml_name, nc=80, seed=0):
 # ------------------------------------------------------------------ end-to-end forward fixtures
 def e2e(tag, yaml_name, shapes):
     m = build(yaml_name)
-    arrs = {'stride': m.stride.numpy()}
+    arrs = {'stride': m.stride.numpy(), 'sd_keys': '\n'.join(m.state_dict().keys()),
+            'sd_shapes': '\n'.join(','.join(str(d) for d in v.shape) for v in m.state_dict().values())}
     for (b, h, w) in shapes:
         x = seeded_images(b, h, w, seed=IMG_SEED)
         layers = []

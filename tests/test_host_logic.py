@@ -1,0 +1,141 @@
+"""CPU-only checks of the host side: the C ABI loads and exports what include/mgdt.h declares, the YAML -> graph rules,
+state_dict compatibility with the reference, argument validation, and the N>1 (gloo, world_size 2) bench path."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as GI
+from mgdt_yolo_amd import _lib
+from mgdt_yolo_amd.models import CONFIGS, get_config
+from mgdt_yolo_amd.nn import tasks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_YAML = '/root/reference/models/v8'
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'mgdt.h')).read()
+    declared = set(re.findall(r'\b(mgdt_[a-z0-9_]+)\s*\(', hdr)) - {'mgdt_view', 'mgdt_stream'}
+    assert declared, 'no declarations parsed'
+    lib = _lib.lib()                       # dlopen; no GPU call
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/mgdt.h but not exported'
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert b'gfx950' in lib.mgdt_version()
+    assert lib.mgdt_conv_packed_bytes(64, 64, 3, _lib.BF16) == 18 * 4 * 1024 + 64 * 4      # 576/32 chunks x 4 cout blocks (+ scale scratch)
+    assert lib.mgdt_nms_workspace_bytes(2, 80, 6400, 0, 30000) == 2 * (8192 + 6400) * 8
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    lib = _lib.lib()
+    v = _lib.View(None, 1, 8, 8, 8, 512, 64, 8, 1)
+    assert lib.mgdt_conv2d_fwd(v, None, None, None, None, None, 3, 1, 1, None, None, v, 0, None) == -4    # null pointers
+    assert b'null' in lib.mgdt_last_error()
+    assert lib.mgdt_nms_fwd(None, 1, 1, 1, 0.5, 0.5, None, 0, 0, 0, 1, 1, 1.0, None, None, None, None, 0, None) == -4
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_builtin_graphs_equal_reference_yaml_files(name):
+    import yaml
+    path = os.path.join(REF_YAML, name + '.yaml')
+    if not os.path.exists(path):
+        pytest.skip('reference tree not present on this box')
+    ref = yaml.safe_load(open(path))
+    mine = get_config(name)
+    for k in ('nc', 'scales', 'backbone', 'head'):
+        assert ref[k] == mine[k]
+
+
+def test_parse_reference_yaml_files():
+    """yaml_model_load + parse_model on the reference's own files (scale from the file stem, tasks.py:702-735)."""
+    path = os.path.join(REF_YAML, 'mspa_c2f_gd_yolov8n.yaml')
+    if not os.path.exists(os.path.join(REF_YAML, 'mspa_c2f_gd_yolov8.yaml')):
+        pytest.skip('reference tree not present on this box')
+    m = tasks.DetectionModel(path, verbose=False)
+    assert m.yaml['scale'] == 'n' and sum(p.numel() for p in m.parameters()) == 1314298
+    assert m.save == [2, 2, 4, 4, 6, 6, 9, 11, 15] and m.stride.tolist() == [8.0]
+    s = tasks.DetectionModel(os.path.join(REF_YAML, 'mspa_c2f_gd_yolov8s.yaml'), verbose=False)
+    assert sum(p.numel() for p in s.parameters()) == 4149424
+
+
+def test_model_structure_and_state_dict_names():
+    m = tasks.DetectionModel(get_config('yolov8', 'n'), verbose=False)
+    assert sum(p.numel() for p in m.parameters()) == 2847732 and m.stride.tolist() == [8.0, 16.0, 32.0]
+    g = tasks.DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n'), verbose=False)
+    keys = set(g.state_dict())
+    for k in ('model.0.conv.weight', 'model.0.bn.running_var', 'model.2.convs.3.conv.weight', 'model.2.bottleneck.0.cv2.bn.bias',
+              'model.2.attention.fc1.weight', 'model.2.attention.fc2.bias', 'model.9.cv2.conv.weight', 'model.11.conv.1.dwconv.weight',
+              'model.11.conv.1.norm.weight', 'model.11.conv.2.grn.gamma', 'model.11.conv.3.pwconv2.bias', 'model.13.cv1.conv.weight',
+              'model.13.cv_fuse.bn.weight', 'model.14.global_act.conv.weight', 'model.15.m.0.cv1.conv.weight', 'model.16.cv2.0.2.bias',
+              'model.16.cv3.0.0.conv.weight', 'model.16.dfl.conv.weight'):
+        assert k in keys, k
+    assert 'model.13.cv2.conv.weight' not in keys            # Identity branches (block.py:312-314)
+    det = g.model[-1]
+    assert (det.nc, det.nl, det.reg_max, det.no) == (80, 1, 4, 96)
+    assert abs(det.cv3[0][2].bias.data[0].item() - np.log(5 / 80 / (640 / 8) ** 2)) < 1e-6   # bias_init, head.py:186
+    assert all(b.eps == 1e-3 and b.momentum == 0.03 for b in g.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    with pytest.raises(KeyError):
+        bad = get_config('yolov8', 'n'); bad['head'][0][2] = 'NoSuchModule'; tasks.DetectionModel(bad, verbose=False)
+
+
+def test_state_dict_matches_reference_keys_and_shapes(golden):
+    for tag, name in GI.E2E_MODELS.items():
+        g = golden('e2e_' + tag)
+        if 'sd_keys' not in g:
+            pytest.skip('fixture without key list')
+        ref = dict(zip(str(g['sd_keys']).split('\n'), [tuple(int(v) for v in s.split(',') if v) for s in str(g['sd_shapes']).split('\n')]))
+        mine = {k: tuple(v.shape) for k, v in tasks.DetectionModel(get_config(name, 'n'), verbose=False).state_dict().items()}
+        assert mine == ref
+
+
+def test_helpers():
+    from mgdt_yolo_amd.yolo.utils.torch_utils import make_divisible
+    assert tasks.guess_model_scale('x/mspa_c2f_gd_yolov8s.yaml') == 's' and tasks.guess_model_scale('foo.yaml') == ''
+    assert make_divisible(33, 8) == 40 and make_divisible(64 * 0.25, 8) == 16
+    assert tasks.yaml_model_load('yolov8n.yaml')['scale'] == 'n'            # built-in graph by name
+    with pytest.raises(FileNotFoundError):
+        tasks.yaml_model_load('nope.yaml')
+
+
+def test_nms_argument_validation_and_cpu_refusal():
+    from mgdt_yolo_amd.yolo.utils.ops import non_max_suppression
+    with pytest.raises(AssertionError, match='Invalid Confidence'):
+        non_max_suppression(torch.zeros(1, 84, 10), conf_thres=1.2)
+    with pytest.raises(AssertionError, match='Invalid IoU'):
+        non_max_suppression(torch.zeros(1, 84, 10), iou_thres=-0.1)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        non_max_suppression(torch.zeros(1, 84, 10))
+    m = tasks.DetectionModel(get_config('yolov8', 'n'), verbose=False).eval()
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from mgdt_yolo_amd import parallel
+    from mgdt_yolo_amd.seeding import seeded_images
+    dist = parallel.init('gloo')
+    r, _, w = parallel.env_rank()
+    x = seeded_images(2, 8, 8, seed=parallel.shard_seed(100, r))          # disjoint shards
+    elapsed = 1.0 + 0.5 * r                                              # rank 1 is the slow one
+    dist.barrier()
+    t = parallel.max_over_ranks(elapsed)
+    q.put((r, float(x.sum()), t, parallel.aggregate_throughput(32, 10, t, w)))
+    dist.destroy_process_group()
+
+
+def test_multi_rank_bench_path_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    ps = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(30) for p in ps]
+    assert res[0][1] != res[1][1]                                         # different data per rank
+    assert res[0][2] == res[1][2] == 1.5                                  # MAX over ranks
+    assert res[0][3] == pytest.approx(2 * 32 * 10 / 1.5)                  # whole-job aggregate
