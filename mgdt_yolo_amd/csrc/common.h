@@ -56,9 +56,26 @@ template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
 }
 
 
+// sigmoid through the hardware exp2 / rcp units (~1 ulp each): the SiLU epilogue must not turn HBM-bound convs VALU-bound
+__device__ __forceinline__ float fast_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
+// exact unsigned division by a runtime constant: q = mulhi(n, mul) >> sh  (n < 2^31), host-side magic numbers
+struct FastDiv { uint32_t mul, sh, d; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  if (d == 1) { f.mul = 0; f.sh = 0; return f; }
+  uint32_t l = 0; while ((1u << l) < d) ++l;            // ceil(log2 d)
+  uint64_t m = ((uint64_t)1 << (32 + l - 1)) / d + 1;     // round-up magic for 31-bit n
+  f.mul = (uint32_t)m; f.sh = l - 1;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
-    case MGDT_ACT_SILU: return v / (1.0f + expf(-v));
+    case MGDT_ACT_SILU: return v * fast_sigmoid(v);
     case MGDT_ACT_RELU: return fmaxf(v, 0.0f);
     case MGDT_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     default: return v;

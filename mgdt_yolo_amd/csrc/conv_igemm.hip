@@ -13,24 +13,7 @@
 //     persistent over pixel tiles and the main loop has no barrier at all.
 //   * fused: second input add (MSPA sp+spx), per-(image,channel) input affine (GRN / attention scale),
 //     bias (folded BN), activation, up to two residual adds, channel-sliced input/output views (chunk/cat).
-#include "common.h"
-
-template <typename T> struct Piece;
-template <> struct Piece<float> { static constexpr int PE = 4; typedef f32x4 frag; };
-template <> struct Piece<bf16> { static constexpr int PE = 8; typedef bf16x8 frag; };
-
-struct ConvArgs {
-  const char* x; long xsn, xsh, xsw;
-  const char* x2; long x2sn, x2sh, x2sw;
-  const float* in_scale; const float* in_shift;
-  const char* wpk; const float* bias;
-  char* y; long ysn, ysh, ysw;
-  const char* r1; long r1sn, r1sh, r1sw;
-  const char* r2; long r2sn, r2sh, r2sw;
-  int N, H, W, Cin, Ho, Wo, Cout;
-  int KS, stride, pad, CP, nchunks, NTtot, act;
-  int M, HoWo, numTiles, seg_chunks, nseg, tab_bytes;
-};
+#include "conv_igemm_kernel.h"
 
 // ------------------------------------------------------------------------------------------------ packing
 template <typename T>
@@ -77,165 +60,6 @@ __global__ void fold_kernel(const float* cb, const float* g, const float* b, con
   bias_out[c] = bo;
 }
 
-// ------------------------------------------------------------------------------------------------ device helpers
-template <typename T> __device__ __forceinline__ typename Piece<T>::frag zero_frag();
-template <> __device__ __forceinline__ f32x4 zero_frag<float>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-template <> __device__ __forceinline__ bf16x8 zero_frag<bf16>() {
-  bf16x8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
-  return z;
-}
-
-template <typename T>
-__device__ __forceinline__ typename Piece<T>::frag frag_add(typename Piece<T>::frag a, typename Piece<T>::frag b) {
-  typename Piece<T>::frag o;
-#pragma unroll
-  for (int i = 0; i < Piece<T>::PE; ++i) o[i] = (T)((float)a[i] + (float)b[i]);
-  return o;
-}
-
-template <typename T>
-__device__ __forceinline__ typename Piece<T>::frag frag_affine(typename Piece<T>::frag a, const float* sc, const float* sh) {
-  typename Piece<T>::frag o;
-#pragma unroll
-  for (int i = 0; i < Piece<T>::PE; ++i) {
-    float v = (float)a[i];
-    if (sc) v *= sc[i];
-    if (sh) v += sh[i];
-    o[i] = (T)v;
-  }
-  return o;
-}
-
-__device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 p, f32x4 acc) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], p[s], acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ f32x4 mma(bf16x8 w, bf16x8 p, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, p, acc, 0, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------------ main kernel
-template <typename T, int NT, int MT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-  typedef typename Piece<T>::frag frag;
-  constexpr int PE = Piece<T>::PE;
-  constexpr int BM = 4 * MT * 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* ptab = (uint32_t*)smem;
-  char* wlds = smem + a.tab_bytes;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int nb0 = blockIdx.y * NT;
-
-  // piece table: (dy, dx, channel offset) per 16-byte K piece; 0xFFFFFFFF = zero padding piece
-  for (int p = tid; p < a.nchunks * 4; p += 256) {
-    int tap = p / a.CP, cp = p % a.CP;
-    uint32_t e = 0xFFFFFFFFu;
-    if (tap < a.KS * a.KS) e = (uint32_t)(tap / a.KS) | ((uint32_t)(tap % a.KS) << 8) | ((uint32_t)(cp * PE) << 16);
-    ptab[p] = e;
-  }
-
-  auto stage = [&](int seg) {
-    const int c0 = seg * a.seg_chunks;
-    const int nc = min(a.seg_chunks, a.nchunks - c0);
-    const int nblk = nc * NT;  // 1 KiB blocks
-    for (int i = tid; i < nblk * 64; i += 256) {
-      int blk = i >> 6, l = i & 63;
-      int kc = blk / NT, nt = blk % NT;
-      const uint4* src = (const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * 1024) + l;
-      ((uint4*)(wlds + (long)blk * 1024))[l] = *src;
-    }
-  };
-  if (a.nseg == 1) stage(0);
-  __syncthreads();
-
-  for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-    int pn[MT], py[MT], px[MT];
-    bool pv[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      int m = tile * BM + (wave * MT + mt) * 16 + r;
-      pv[mt] = m < a.M;
-      int mm = pv[mt] ? m : 0;
-      int n = mm / a.HoWo, rem = mm - n * a.HoWo;
-      int oy = rem / a.Wo;
-      pn[mt] = n; py[mt] = oy; px[mt] = rem - oy * a.Wo;
-    }
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int seg = 0; seg < a.nseg; ++seg) {
-      if (a.nseg > 1) {
-        __syncthreads();
-        stage(seg);
-        __syncthreads();
-      }
-      const int c0 = seg * a.seg_chunks;
-      const int nc = min(a.seg_chunks, a.nchunks - c0);
-      for (int kc = 0; kc < nc; ++kc) {
-        const uint32_t e = ptab[(c0 + kc) * 4 + g];
-        const bool pvalid = e != 0xFFFFFFFFu;
-        const int dy = e & 0xFF, dx = (e >> 8) & 0xFF, ch = (int)(e >> 16);
-        frag P[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          int iy = py[mt] * a.stride - a.pad + dy, ix = px[mt] * a.stride - a.pad + dx;
-          bool ok = pvalid && pv[mt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-          frag v = zero_frag<T>();
-          if (ok) {
-            v = *(const frag*)(a.x + (pn[mt] * a.xsn + iy * a.xsh + ix * a.xsw + ch) * (long)sizeof(T));
-            if (a.x2) v = frag_add<T>(v, *(const frag*)(a.x2 + (pn[mt] * a.x2sn + iy * a.x2sh + ix * a.x2sw + ch) * (long)sizeof(T)));
-            if (a.in_scale || a.in_shift)
-              v = frag_affine<T>(v, a.in_scale ? a.in_scale + (long)pn[mt] * a.Cin + ch : nullptr,
-                                 a.in_shift ? a.in_shift + ch : nullptr);
-          }
-          P[mt] = v;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const frag Wf = *(const frag*)(wlds + ((long)(kc * NT + nt) * 64 + lane) * 16);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma(Wf, P[mt], acc[nt][mt]);
-        }
-      }
-    }
-
-    // epilogue: lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (!pv[mt]) continue;
-      const long yo = pn[mt] * a.ysn + py[mt] * a.ysh + px[mt] * a.ysw;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = (nb0 + nt) * 16 + 4 * g;
-        if (co >= a.Cout) continue;
-        const f32x4 b = *(const f32x4*)(a.bias + co);
-        f32x4 v = acc[nt][mt];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j] + b[j], a.act);
-        if (a.r1) {
-          f32x4 q = load4<T>((const T*)a.r1 + pn[mt] * a.r1sn + py[mt] * a.r1sh + px[mt] * a.r1sw + co);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += q[j];
-        }
-        if (a.r2) {
-          f32x4 q = load4<T>((const T*)a.r2 + pn[mt] * a.r2sn + py[mt] * a.r2sh + px[mt] * a.r2sw + co);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += q[j];
-        }
-        store4<T>((T*)a.y + yo + co, v);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 static inline int piece_elems(int dtype) { return dtype == MGDT_BF16 ? 8 : 4; }
 
@@ -274,24 +98,13 @@ extern "C" int mgdt_conv_pack(const float* w, const float* cb, const float* g, c
 }
 
 template <typename T, int NT, int MT>
-static int launch_igemm(const ConvArgs& a, int gx, int gy, size_t lds, hipStream_t st) {
-  static bool attr_set = false;  // idempotent; racing setters write the same value
-  auto kern = conv_igemm_kernel<T, NT, MT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  kern<<<dim3(gx, gy), 256, lds, st>>>(a);
-  MGDT_CHECK_LAUNCH("conv2d_fwd");
-  return MGDT_OK;
-}
+int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st);   // defined in conv_igemm_inst_*.hip
 
 template <typename T>
-static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, size_t lds, hipStream_t st) {
+static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, int threads, size_t lds, hipStream_t st) {
 #define CASE(nt, mt) \
-  if (NT == nt && MT == mt) return launch_igemm<T, nt, mt>(a, gx, gy, lds, st);
-  CASE(1, 4) CASE(2, 4) CASE(3, 4) CASE(4, 4) CASE(5, 2) CASE(6, 2) CASE(8, 2) CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(4, 2)
+  if (NT == nt && MT == mt) return launch_igemm<T, nt, mt>(a, gx, gy, threads, lds, st);
+  CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
 #undef CASE
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: no kernel for NT=%d MT=%d", NT, MT);
 }
@@ -332,23 +145,34 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   long M = (long)a.N * Ho * Wo;
   if (M > 0x7fffffffL || (long)x->n * x->sn > 0x7fffffffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: problem too large");
   a.M = (int)M; a.HoWo = Ho * Wo;
+  auto extent = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * (long)dtype_size(dtype); };
+  if (extent(x) >= 0x7fffffffL || (x2 && x2->p && extent(x2) >= 0x7fffffffL)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: input view spans >= 2 GiB");
+  a.x_bytes = (uint32_t)extent(x); a.x2_bytes = (x2 && x2->p) ? (uint32_t)extent(x2) : 0u;
+  a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
 
-  // tile choice: NT = cout blocks per workgroup (prefer all of them: activations are then read once)
+  // tile choice: NT = cout blocks per workgroup - as many as divide NTtot and keep the whole weight panel in LDS
+  // (activations are then read NTtot/NT times; once when NT == NTtot), fewer when the grid would starve the 256 CUs
+  const int LDS_PANEL_KIB = 128;
   int NT = 1;
   for (int c : {8, 6, 5, 4, 3, 2, 1})
-    if (a.NTtot % c == 0) { NT = c; break; }
-  int MT = NT <= 4 ? 4 : 2;
-  auto wgs = [&](int nt, int mt) { return (long)cdiv(M, 64 * mt) * (a.NTtot / nt); };
-  if (MT == 4 && wgs(NT, 4) < 512) MT = 2;                      // small maps: more, smaller tiles
-  while (wgs(NT, MT) < 256 && NT > 1 && NT % 2 == 0) NT /= 2;   // ... and split the couts over workgroups
-  a.numTiles = cdiv(M, 64 * MT);
-  a.tab_bytes = ((a.nchunks * 16) + 15) & ~15;
+    if (a.NTtot % c == 0 && a.nchunks * c <= LDS_PANEL_KIB) { NT = c; break; }
+  const int MT = 2;   // MT=2 with depth-4 prefetch measured faster than MT=4 on every layer of the target nets
+  int waves = 8;
+  auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
+  if (wgs(NT, waves) < 512) waves = 4;                              // small maps: more, smaller tiles
+  while (wgs(NT, waves) < 256 && NT > 1 && NT % 2 == 0) NT /= 2;    // ... and split the couts over workgroups
+  {   // experiment knob (not part of the ABI)
+    const char* e;
+    if ((e = getenv("MGDT_CONV_WAVES"))) waves = atoi(e);
+  }
+  a.numTiles = cdiv(M, 16 * waves * MT);
+  a.tab_bytes = (a.nchunks + 3) / 4 * 4 * 4 * 8;   // uint2 per piece, padded to a multiple of 4 chunks (>= nchp in the kernel)
   size_t panel = (size_t)a.nchunks * NT * 1024;
-  if (panel + a.tab_bytes <= 128 * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
-  else { a.seg_chunks = std::max(1, 64 / NT); a.nseg = cdiv(a.nchunks, a.seg_chunks); }
+  if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
+  else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
   size_t lds = a.tab_bytes + (size_t)a.seg_chunks * NT * 1024;
-  int gx = std::min(a.numTiles, a.nseg == 1 ? 1024 : 4096), gy = a.NTtot / NT;
+  int gx = std::min(a.numTiles, waves == 8 ? 512 : 1024), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
-  if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, lds, st);
-  return dispatch_igemm<bf16>(a, NT, MT, gx, gy, lds, st);
+  if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, waves * 64, lds, st);
+  return dispatch_igemm<bf16>(a, NT, MT, gx, gy, waves * 64, lds, st);
 }

@@ -1,0 +1,297 @@
+// Device side of the implicit-GEMM convolution (see conv_igemm.hip for the design notes); included by the per-dtype
+// instantiation units conv_igemm_inst_*.hip so that the 84 template instantiations compile in parallel.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+template <typename T> struct Piece;
+template <> struct Piece<float> { static constexpr int PE = 4; typedef f32x4 frag; };
+template <> struct Piece<bf16> { static constexpr int PE = 8; typedef bf16x8 frag; };
+
+struct ConvArgs {
+  const char* x; long xsn, xsh, xsw;
+  const char* x2; long x2sn, x2sh, x2sw;
+  const float* in_scale; const float* in_shift;
+  const char* wpk; const float* bias;
+  char* y; long ysn, ysh, ysw;
+  const char* r1; long r1sn, r1sh, r1sw;
+  const char* r2; long r2sn, r2sh, r2sw;
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int KS, stride, pad, CP, nchunks, NTtot, act;
+  int M, HoWo, numTiles, seg_chunks, nseg, tab_bytes;
+  FastDiv fd_howo, fd_wo;
+  uint32_t x_bytes, x2_bytes;   // addressable extent of the x / x2 views (buffer descriptor range)
+};
+
+// ------------------------------------------------------------------------------------------------ device helpers
+template <typename T> __device__ __forceinline__ typename Piece<T>::frag zero_frag();
+template <> __device__ __forceinline__ f32x4 zero_frag<float>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ bf16x8 zero_frag<bf16>() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+  return z;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Piece<T>::frag frag_add(typename Piece<T>::frag a, typename Piece<T>::frag b) {
+  typename Piece<T>::frag o;
+#pragma unroll
+  for (int i = 0; i < Piece<T>::PE; ++i) o[i] = (T)((float)a[i] + (float)b[i]);
+  return o;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Piece<T>::frag frag_affine(typename Piece<T>::frag a, const float* sc, const float* sh) {
+  typename Piece<T>::frag o;
+#pragma unroll
+  for (int i = 0; i < Piece<T>::PE; ++i) {
+    float v = (float)a[i];
+    if (sc) v *= sc[i];
+    if (sh) v += sh[i];
+    o[i] = (T)v;
+  }
+  return o;
+}
+
+__device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 p, f32x4 acc) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], p[s], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x4 mma(bf16x8 w, bf16x8 p, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, p, acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ main kernel
+// blockDim.x = 64 * nwaves (4, 8 or 16 waves); a workgroup covers nwaves*MT*16 output pixels x NT*16 output channels per
+// tile and is PERSISTENT over tiles blockIdx.x + j*gridDim.x.  Per tile the K-chunks are padded to a multiple of D steps so
+// that step j always uses register set j % D (compile-time indices).  At step j the loads of step j+D-1 are issued; in the
+// tile's last group they belong to the NEXT tile, so its first loads are in flight while this tile finishes its MFMAs and
+// runs its epilogue.  The step body is a handful of integer instructions: one 8-byte table read, per row block a bit test
+// on the pixel's tap-validity mask + one add, a bounds-checked buffer load (zero fill for padding), NT ds_read_b128 at
+// immediate offsets from a running LDS pointer, NT*MT MFMAs.
+struct TileState { int xo; uint32_t vm; long yo; int pn, iy0, ix0; };
+
+template <typename T, int NT, int MT, int D, bool EXTRA, bool MULTI>
+__global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
+  typedef typename Piece<T>::frag frag;
+  constexpr int PE = Piece<T>::PE;
+  constexpr int L = D - 1;             // look-ahead in (padded) steps
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint2* ptab = (uint2*)smem;          // per 16-byte K piece: {byte offset of (tap, channel) inside the x view, tap index}
+  char* wlds = smem + a.tab_bytes;
+
+  const int nthr = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int nb0 = blockIdx.y * NT;
+  const int BM = (nthr >> 6) * MT * 16;
+  const int xsn = (int)a.xsn, xsh = (int)a.xsh, xsw = (int)a.xsw;
+  const int nchp = (a.nchunks + D - 1) / D * D;
+
+  for (int p = tid; p < nchp * 4; p += nthr) {   // table padded to nchp chunks: padding pieces carry tap 31 (never valid)
+    int tap = p / a.CP, cp = p % a.CP;
+    uint2 e = make_uint2(0u, 31u);
+    if (tap < a.KS * a.KS) e = make_uint2((uint32_t)(((tap / a.KS) * xsh + (tap % a.KS) * xsw + cp * PE) * (int)sizeof(T)), (uint32_t)tap);
+    ptab[p] = e;
+  }
+  __syncthreads();
+
+  auto stage = [&](int seg) __attribute__((always_inline)) {
+    const int c0 = seg * a.seg_chunks;
+    const int nc = min(a.seg_chunks, a.nchunks - c0);
+    const int nblk = nc * NT;  // 1 KiB blocks
+    for (int i = tid; i < nblk * 64; i += nthr) {
+      int blk = i >> 6, l = i & 63;
+      int kc = blk / NT, nt = blk % NT;
+      const uint4* src = (const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * 1024) + l;
+      ((uint4*)(wlds + (long)blk * 1024))[l] = *src;
+    }
+  };
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? a.x2_bytes : 0u, 0x00020000);
+
+  auto setup = [&](int tile, TileState(&S)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int m = tile * BM + (wave * MT + mt) * 16 + r;
+      const bool pv = tile < a.numTiles && m < a.M;
+      int mm = pv ? m : 0;
+      int n = (int)fdiv((uint32_t)mm, a.fd_howo), rem = mm - n * a.HoWo;
+      int oy = (int)fdiv((uint32_t)rem, a.fd_wo), ox = rem - oy * a.Wo;
+      TileState t;
+      t.pn = n;
+      t.iy0 = oy * a.stride - a.pad;
+      t.ix0 = ox * a.stride - a.pad;
+      t.xo = (n * xsn + t.iy0 * xsh + t.ix0 * xsw) * (int)sizeof(T);
+      t.yo = pv ? n * a.ysn + oy * a.ysh + ox * a.ysw : -1;
+      uint32_t rm = 0, cm = 0, mask = 0;
+      for (int d = 0; d < a.KS; ++d) {
+        rm |= (uint32_t)((unsigned)(t.iy0 + d) < (unsigned)a.H) << d;
+        cm |= (uint32_t)((unsigned)(t.ix0 + d) < (unsigned)a.W) << d;
+      }
+      for (int d = 0; d < a.KS; ++d)
+        if ((rm >> d) & 1u) mask |= cm << (d * a.KS);
+      t.vm = pv ? mask : 0u;   // bit t set <=> tap t of this pixel lies inside the image (0 for rows past M)
+      S[mt] = t;
+    }
+  };
+
+  // activation fragments of one K-chunk (table entry e): each lane fetches the 16 bytes it feeds to the MFMA.  Padding taps /
+  // tail rows / padded chunks get an out-of-range offset and the hardware returns zeros: no branch, no select.
+  auto load_chunk = [&](const uint2 e, const TileState(&S)[MT], frag(&P)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool ok = (S[mt].vm >> e.y) & 1u;
+      const uint32_t off = ok ? (uint32_t)S[mt].xo + e.x : 0xFFFFFFF0u;
+      frag v = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+      if (EXTRA) {
+        const int dy = (int)e.y / a.KS, dx = (int)e.y - dy * a.KS;
+        const int ch = ((int)e.x / (int)sizeof(T) - dy * xsh - dx * xsw);
+        if (a.x2) {
+          const uint32_t off2 = ok ? (uint32_t)((S[mt].pn * a.x2sn + (S[mt].iy0 + dy) * a.x2sh + (S[mt].ix0 + dx) * a.x2sw + ch) * (long)sizeof(T)) : 0xFFFFFFF0u;
+          v = frag_add<T>(v, __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(x2rs, off2, 0, 0)));
+        }
+        if (ok && (a.in_scale || a.in_shift))
+          v = frag_affine<T>(v, a.in_scale ? a.in_scale + (long)S[mt].pn * a.Cin + ch : nullptr, a.in_shift ? a.in_shift + ch : nullptr);
+      }
+      P[mt] = v;
+    }
+  };
+
+  f32x4 acc[NT][MT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](const char* wp, const frag(&P)[MT]) __attribute__((always_inline)) {   // wp: this lane's slot of the chunk's weight blocks
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const frag Wf = *(const frag*)(wp + nt * 1024);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma(Wf, P[mt], acc[nt][mt]);
+    }
+  };
+  // lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r); the activation switch is hoisted out of the loops
+  auto epilogue_act = [&](const TileState(&S)[MT], auto actf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (S[mt].yo < 0) continue;
+      long r1o = 0, r2o = 0;
+      if (a.r1 || a.r2) {
+        int oy = (S[mt].iy0 + a.pad) / a.stride, ox = (S[mt].ix0 + a.pad) / a.stride;
+        r1o = S[mt].pn * a.r1sn + oy * a.r1sh + ox * a.r1sw;
+        r2o = S[mt].pn * a.r2sn + oy * a.r2sh + ox * a.r2sw;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = (nb0 + nt) * 16 + 4 * g;
+        if (co >= a.Cout) continue;
+        const f32x4 b = *(const f32x4*)(a.bias + co);
+        f32x4 v = acc[nt][mt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = actf(v[j] + b[j]);
+        if (a.r1) v += load4<T>((const T*)a.r1 + r1o + co);
+        if (a.r2) v += load4<T>((const T*)a.r2 + r2o + co);
+        store4<T>((T*)a.y + S[mt].yo + co, v);
+      }
+    }
+  };
+  auto epilogue = [&](const TileState(&S)[MT]) __attribute__((always_inline)) {
+    switch (a.act) {
+      case MGDT_ACT_SILU: epilogue_act(S, [](float v) { return v * fast_sigmoid(v); }); break;
+      case MGDT_ACT_RELU: epilogue_act(S, [](float v) { return fmaxf(v, 0.f); }); break;
+      case MGDT_ACT_GELU: epilogue_act(S, [](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }); break;
+      default: epilogue_act(S, [](float v) { return v; }); break;
+    }
+  };
+
+  // ---- persistent stream over my tiles ----
+  TileState cur[MT], nxt[MT];
+  int tile = blockIdx.x;
+  setup(tile, cur);
+  frag P[D][MT];
+  const uint2* tab_g = ptab + g;                 // this lane's column of the piece table
+  load_chunk(tab_g[0], cur, P[0]);               // first loads in flight BEFORE the weight panel is staged
+  if constexpr (L > 1) load_chunk(tab_g[4], cur, P[1]);
+  if constexpr (L > 2) load_chunk(tab_g[8], cur, P[2]);
+  if (!MULTI) { stage(0); __syncthreads(); }
+  const char* const wlane = wlds + lane * 16;
+  constexpr bool multi = MULTI;   // weight panel staged in K segments (only when even one cout block does not fit in LDS)
+
+  for (; tile < a.numTiles; tile += gridDim.x) {
+    zero_acc();
+    const uint2* tp = tab_g + 4 * L;             // table entry of the chunk that step 0 prefetches
+    const char* wp = wlane;                      // weight blocks of the chunk that step 0 computes
+    int kl = 0;                                  // chunk index inside the staged weight segment (multi-segment panels only)
+    // one step: prefetch (`ahead` = table entry of a later chunk of THIS tile), then the MFMAs of chunk j
+    auto step_cur = [&](int j, auto dtag) __attribute__((always_inline)) {
+      constexpr int d = decltype(dtag)::value;
+      load_chunk(*tp, cur, P[(d + L) % D]);
+      tp += 4;
+      if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
+      compute(wp, P[d]);
+      wp += NT * 1024;
+      if (multi && ++kl == a.seg_chunks) kl = 0;
+    };
+    int j0 = 0;
+    for (; j0 < nchp - D; j0 += D) {             // every chunk computed here is real (nchp - D < nchunks)
+      step_cur(j0, std::integral_constant<int, 0>{});
+      step_cur(j0 + 1, std::integral_constant<int, 1>{});
+      if constexpr (D > 2) step_cur(j0 + 2, std::integral_constant<int, 2>{});
+      if constexpr (D > 3) step_cur(j0 + 3, std::integral_constant<int, 3>{});
+    }
+    // last group: step 0 prefetches this tile's final (possibly padded) chunk, steps d >= 1 the NEXT tile's chunk d-1
+    setup(tile + gridDim.x, nxt);
+    step_cur(j0, std::integral_constant<int, 0>{});
+    auto step_last = [&](int j, auto dtag) __attribute__((always_inline)) {
+      constexpr int d = decltype(dtag)::value;
+      load_chunk(tab_g[4 * (d - 1)], nxt, P[(d + L) % D]);
+      if (j < a.nchunks) {
+        if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
+        compute(wp, P[d]);
+        wp += NT * 1024;
+        if (multi && ++kl == a.seg_chunks) kl = 0;
+      }
+    };
+    step_last(j0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (D > 2) step_last(j0 + 2, std::integral_constant<int, 2>{});
+    if constexpr (D > 3) step_last(j0 + 3, std::integral_constant<int, 3>{});
+    epilogue(cur);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
+  }
+}
+
+template <typename T, int NT, int MT>
+int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st) {
+  static bool attr_set = false;  // idempotent; racing setters write the same value
+  constexpr bool M1 = NT == 1;   // the segmented-panel variant exists for NT == 1 only (host never asks for it otherwise)
+  const void* ks[8] = {(const void*)conv_igemm_kernel<T, NT, MT, 2, false, false>, (const void*)conv_igemm_kernel<T, NT, MT, 4, false, false>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, false>,  (const void*)conv_igemm_kernel<T, NT, MT, 4, true, false>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, false, M1>,    (const void*)conv_igemm_kernel<T, NT, MT, 4, false, M1>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, M1>,     (const void*)conv_igemm_kernel<T, NT, MT, 4, true, M1>};
+  if (!attr_set) {
+    for (const void* k : ks) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    attr_set = true;
+  }
+  const int D = a.nchunks >= 3 ? 4 : 2;        // look-ahead D-1 <= nchunks
+  const bool extra = a.x2 || a.in_scale || a.in_shift;
+  void* kargs[] = {(void*)&a};
+  hipError_t le = hipLaunchKernel(ks[(a.nseg > 1 ? 4 : 0) + (extra ? 2 : 0) + (D == 4 ? 1 : 0)], dim3(gx, gy), dim3(threads), kargs, lds, st);
+  if (le != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv2d: launch: %s", hipGetErrorString(le));
+  MGDT_CHECK_LAUNCH("conv2d_fwd");
+  return MGDT_OK;
+}
+
+
+#define MGDT_IGEMM_INSTANTIATE(T, nt) template int launch_igemm<T, nt, 2>(const ConvArgs&, int, int, int, size_t, hipStream_t);

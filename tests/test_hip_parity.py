@@ -78,6 +78,7 @@ CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants belo
     (128, 256, 3, 2, 10, 10), (64, 16, 3, 1, 20, 20), (64, 80, 3, 1, 16, 16), (80, 80, 3, 1, 16, 16), (80, 64, 1, 1, 9, 9),
     (160, 128, 1, 1, 10, 10), (512, 256, 1, 1, 5, 5), (480, 96, 1, 1, 10, 10), (96, 384, 1, 1, 10, 6), (384, 96, 1, 1, 10, 6),
     (192, 64, 1, 1, 12, 12), (32, 256, 1, 1, 7, 7), (256, 256, 1, 1, 6, 5), (24, 40, 3, 1, 11, 7), (16, 48, 1, 1, 5, 5),
+    (512, 16, 3, 1, 6, 6), (544, 32, 3, 2, 9, 7),   # K panel larger than LDS even for one cout block -> segmented-panel kernel
 ]
 
 
