@@ -93,7 +93,9 @@ int mgdt_copy_fwd(const mgdt_view* x, int x_dtype, const mgdt_view* y, int y_dty
 /* ---- ConvNeXtV2 block pieces (nn/modules/convnextv2.py:48-77, nn/modules/utils.py:145-182) -------------
  * dwln: y = LayerNorm_c(dwconv7x7(x) + b) * ln_w + ln_b   (eps 1e-6), dw_w is [49][c] fp32.
  * grn_stats: t (n,h,w,c) -> scale[n][c] = gamma[c]*Nx[n,c] + 1, with Nx = ||t||_2(h,w) / (mean_c + 1e-6);
- *            ws: fp32 [n][c] scratch.  (shift[c] = beta[c] is passed to mgdt_conv2d_fwd directly.)        */
+ *            ws: fp32 [n][MGDT_GRN_SPLITS][c] scratch (per pixel-band partial sums, fixed reduction order).
+ *            (shift[c] = beta[c] is passed to mgdt_conv2d_fwd directly.)                                   */
+#define MGDT_GRN_SPLITS 8
 int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                         float eps, const mgdt_view* y, int dtype, mgdt_stream s);
 int mgdt_grn_stats_fwd(const mgdt_view* t, const float* gamma, float* ws, float* scale, int dtype, mgdt_stream s);

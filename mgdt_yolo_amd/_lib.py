@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libmgdt_hip.so')
 F32, BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 SPR_SPLITS = 16
+GRN_SPLITS = 8
 
 
 class View(C.Structure):

@@ -99,6 +99,58 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TX* __restrict__
     if (co0 + j < Cout) yp[(co0 + j) * ysc] = (TY)act_apply(acc[j] + bias[co0 + j], act);
 }
 
+// Stem specialisation (cin <= 4, k = 3): the caller's NCHW fp32 image is read in place, weights sit in LDS (broadcast reads),
+// each thread produces 16 consecutive NHWC output channels of one pixel and stores them as 16-byte vectors.
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const TX* __restrict__ x, long xsn, long xsh, long xsw, long xsc,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, TY* __restrict__ y,
+                                                        long ysn, long ysh, long ysw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                                                        int stride, int act) {
+  __shared__ __attribute__((aligned(16))) float wl[9 * 4 * 16 + 16];
+  const int co0 = blockIdx.y * 16;
+  for (int i = threadIdx.x; i < 9 * Cin * 16; i += 256) wl[i] = w[(long)(i / 16) * Cout + co0 + (i % 16)];
+  if (threadIdx.x < 16) wl[9 * 4 * 16 + threadIdx.x] = bias[co0 + threadIdx.x];
+  __syncthreads();
+  long m = blockIdx.x * 256L + threadIdx.x;
+  long M = (long)N * Ho * Wo;
+  if (m >= M) return;
+  int n = (int)(m / ((long)Ho * Wo));
+  int rem = (int)(m - (long)n * Ho * Wo);
+  int oy = rem / Wo, ox = rem - oy * Wo;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = wl[9 * 4 * 16 + j];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy * stride - 1 + ky;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = ox * stride - 1 + kx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const TX* xp = x + n * xsn + iy * xsh + ix * xsw;
+      for (int ci = 0; ci < Cin; ++ci) {
+        float xv = (float)xp[ci * xsc];
+        const f32x4* wv = (const f32x4*)(wl + ((ky * 3 + kx) * Cin + ci) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t = wv[q];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q * 4 + j] = fmaf(xv, t[j], acc[q * 4 + j]);
+        }
+      }
+    }
+  }
+  TY* yp = y + n * ysn + oy * ysh + ox * ysw + co0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_apply(acc[q * 4 + j], act);
+    store4<TY>(yp + q * 4, v);
+  }
+}
+
 extern "C" int mgdt_conv2d_direct_fwd(const mgdt_view* x, int x_dtype, const float* w, const float* bias, int k, int stride,
                                       int groups, int act, const mgdt_view* y, int dtype, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y) || !w || !bias) MGDT_FAIL(MGDT_BAD_ARG, "conv2d_direct: null/empty argument");
@@ -108,6 +160,19 @@ extern "C" int mgdt_conv2d_direct_fwd(const mgdt_view* x, int x_dtype, const flo
   const int Ho = (x->h + 2 * pad - k) / stride + 1, Wo = (x->w + 2 * pad - k) / stride + 1;
   if (y->n != x->n || y->h != Ho || y->w != Wo) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d_direct: y is %dx%dx%d, expected %dx%dx%d", y->n, y->h, y->w, x->n, Ho, Wo);
   long M = (long)x->n * Ho * Wo;
+  hipStream_t st0 = (hipStream_t)s;
+  if (k == 3 && groups == 1 && x->c <= 4 && y->c % 16 == 0 && y->sc == 1 && y->sw % 4 == 0 && y->sh % 4 == 0 && y->sn % 4 == 0 &&
+      (uintptr_t)y->p % 16 == 0 && x_dtype == MGDT_F32) {   // stem fast path
+    dim3 sg(cdiv(M, 256), y->c / 16);
+    if (dtype == MGDT_BF16)
+      conv_stem_kernel<float, bf16><<<sg, 256, 0, st0>>>((const float*)x->p, x->sn, x->sh, x->sw, x->sc, w, bias, (bf16*)y->p, y->sn, y->sh, y->sw, x->n,
+                                                          x->h, x->w, x->c, Ho, Wo, y->c, stride, act);
+    else
+      conv_stem_kernel<float, float><<<sg, 256, 0, st0>>>((const float*)x->p, x->sn, x->sh, x->sw, x->sc, w, bias, (float*)y->p, y->sn, y->sh, y->sw, x->n,
+                                                           x->h, x->w, x->c, Ho, Wo, y->c, stride, act);
+    MGDT_CHECK_LAUNCH("conv2d_direct_fwd(stem)");
+    return MGDT_OK;
+  }
   constexpr int COB = 16;
   dim3 grid(cdiv(M, 256), cdiv(y->c, COB));
   hipStream_t st = (hipStream_t)s;

@@ -11,6 +11,8 @@
 // IoU arithmetic is the torchvision CPU kernel's, in IEEE fp32 with FP contraction off (this file is compiled
 // with -ffp-contract=off) on boxes offset by cls*max_wh in fp32 exactly as ops.py:247-248 does, so kept indices
 // are bit-exact with the CPU oracle.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define NMS_THREADS 1024
@@ -18,6 +20,7 @@
 typedef unsigned long long u64;
 
 struct NmsArgs {
+  int dbg;
   const float* pred;
   int n, nc, A;
   float conf, iou;
@@ -44,6 +47,31 @@ __device__ __forceinline__ bool class_ok(int c, const int32_t* classes, int n_cl
   return false;
 }
 
+// Best class per anchor (first maximal index, ops.py:225-226) for the whole batch at full-chip parallelism; one thread per
+// anchor, loads are anchor-contiguous (coalesced) and independent across classes (unrolled, many in flight).
+__global__ __launch_bounds__(256) void nms_best_kernel(const NmsArgs a) {
+  const int img = blockIdx.y, an = blockIdx.x * 256 + threadIdx.x;
+  if (an >= a.A) return;
+  const float* P = a.pred + (long)img * (4 + a.nc) * a.A + (long)4 * a.A + an;
+  float best = P[0];
+  int bc = 0;
+  int c = 1;
+  for (; c + 8 <= a.nc; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = P[(long)(c + k) * a.A];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (v[k] > best) { best = v[k]; bc = c + k; }
+  }
+  for (; c < a.nc; ++c) {
+    float v = P[(long)c * a.A];
+    if (v > best) { best = v; bc = c; }
+  }
+  u64* akeys = a.ws + (long)img * a.ws_per_image + a.cap_pow2;
+  akeys[an] = (best > a.conf && class_ok(bc, a.classes, a.n_classes)) ? make_key(best, (unsigned)an * a.nc + bc) : KEY_NONE;
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int img = blockIdx.x, tid = threadIdx.x;
@@ -65,19 +93,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     }
     return akeys[i];
   };
-  if (!a.multi_label) {   // best class per anchor (first maximal index), ops.py:225-226
-    for (int an = tid; an < a.A; an += NMS_THREADS) {
-      float best = P[(long)4 * a.A + an];
-      int bc = 0;
-      for (int c = 1; c < a.nc; ++c) {
-        float sc = P[(long)(4 + c) * a.A + an];
-        if (sc > best) { best = sc; bc = c; }
-      }
-      akeys[an] = (best > a.conf && class_ok(bc, a.classes, a.n_classes)) ? make_key(best, (unsigned)an * a.nc + bc) : KEY_NONE;
-    }
-    __syncthreads();
-  }
-
+  unsigned long long T0 = wall_clock64();
   // ---- count candidates
   if (tid == 0) { s_cnt = 0; s_sel = 0; }
   __syncthreads();
@@ -121,85 +137,168 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     kth = prefix;   // keys are unique (candidate id in the low word): exactly K keys are <= kth
   }
 
+  unsigned long long T1 = wall_clock64();
   // ---- compact the selected keys into the sort buffer (unordered), pad to a power of two
   unsigned np2 = 1;
   while (np2 < K) np2 <<= 1;
   u64* sbuf = (np2 <= NMS_LDS_KEYS) ? (u64*)smem : gbuf;
   if (tid == 0) s_sel = 0;
   __syncthreads();
-  for (long i = tid; i < total; i += NMS_THREADS) {
-    u64 k = key_at(i);
-    if (k != KEY_NONE && k <= kth) sbuf[atomicAdd(&s_sel, 1u)] = k;
+  for (long base = 0; base < total; base += NMS_THREADS) {   // wave-aggregated: one LDS atomic per wave, not per key
+    const long i = base + tid;
+    const u64 k = i < total ? key_at(i) : KEY_NONE;
+    const bool sel = k != KEY_NONE && k <= kth;
+    const u64 m = __ballot(sel);
+    unsigned wbase = 0;
+    if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_sel, (unsigned)__popcll(m));
+    wbase = __shfl(wbase, 0);
+    if (sel) sbuf[wbase + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = k;
   }
   for (unsigned i = K + tid; i < np2; i += NMS_THREADS) sbuf[i] = KEY_NONE;
   __syncthreads();
 
-  // ---- bitonic sort ascending (== descending score, ascending candidate id)
-  for (unsigned k2 = 2; k2 <= np2; k2 <<= 1) {
-    for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-      for (unsigned i = tid; i < np2; i += NMS_THREADS) {
-        unsigned ixj = i ^ j;
-        if (ixj > i) {
-          u64 x = sbuf[i], y = sbuf[ixj];
-          bool up = (i & k2) == 0;
-          if ((x > y) == up) { sbuf[i] = y; sbuf[ixj] = x; }
+  unsigned long long T2 = wall_clock64();
+  // ---- bitonic sort ascending (== descending score, ascending candidate id).  Every thread owns np2/2/1024 disjoint pairs per
+  // pass and issues all its loads before the compare-exchanges (independent LDS accesses in flight instead of a dependent
+  // chain); the LDS case is a separate instantiation so the compiler emits ds_read/ds_write_b64, not flat accesses.
+  auto bitonic = [&](auto* buf) __attribute__((always_inline)) {
+    const unsigned npairs = np2 >> 1;
+    const unsigned blk = np2 / (NMS_THREADS / 64);          // contiguous elements owned by one wave in the wave-local passes
+    const bool local_ok = blk >= 128;
+    const unsigned wbase = (tid >> 6) * blk, ln = tid & 63;
+    for (unsigned k2 = 2; k2 <= np2; k2 <<= 1) {
+      for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+        if (local_ok && j < blk) {
+          // both partners lie inside one wave's block: no workgroup barrier (a wave's LDS accesses complete in order)
+          for (unsigned p0 = 0; p0 < (blk >> 1); p0 += 256) {
+            u64 x[4], y[4];
+            unsigned lo[4];
+            bool act[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const unsigned p = p0 + t * 64 + ln;
+              act[t] = p < (blk >> 1);
+              lo[t] = wbase + (((p & ~(j - 1)) << 1) | (p & (j - 1)));
+              if (act[t]) { x[t] = buf[lo[t]]; y[t] = buf[lo[t] | j]; }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (act[t]) {
+                const bool up = (lo[t] & k2) == 0;
+                if ((x[t] > y[t]) == up) { buf[lo[t]] = y[t]; buf[lo[t] | j] = x[t]; }
+              }
+            }
+          }
+          if (j == 1) __syncthreads();                       // stage done: the next stage may start with a cross-wave pass
+        } else {
+          for (unsigned p0 = 0; p0 < npairs; p0 += NMS_THREADS * 4) {
+            u64 x[4], y[4];
+            unsigned lo[4];
+            bool act[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const unsigned p = p0 + t * NMS_THREADS + tid;
+              act[t] = p < npairs;
+              lo[t] = ((p & ~(j - 1)) << 1) | (p & (j - 1));     // index with bit log2(j) cleared
+              if (act[t]) { x[t] = buf[lo[t]]; y[t] = buf[lo[t] | j]; }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (act[t]) {
+                const bool up = (lo[t] & k2) == 0;
+                if ((x[t] > y[t]) == up) { buf[lo[t]] = y[t]; buf[lo[t] | j] = x[t]; }
+              }
+            }
+          }
+          __syncthreads();
         }
+      }
+    }
+  };
+  if (np2 <= NMS_LDS_KEYS) bitonic((u64*)smem);
+  else bitonic(gbuf);
+
+  unsigned long long T3 = wall_clock64();
+  // ---- greedy suppression, all 16 waves: 1024 sorted candidates per round.
+  //   phase A (parallel): every lane tests its candidate against the boxes kept in earlier rounds (LDS broadcast reads);
+  //   phase B (wave after wave, in score order): a wave first tests against the boxes kept earlier in THIS round, then
+  //   resolves its 64 candidates with ballot + shuffles, appends the survivors to the kept list and writes the output rows.
+  float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
+  unsigned* kidx = (unsigned*)(kb + 5 * a.max_det);                  // sorted position of each kept box
+  __shared__ int s_nkept;
+  if (tid == 0) s_nkept = 0;
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int md = a.max_det;
+  auto suppressed_by = [&](int k, float bx1, float by1, float bx2, float by2, float area) -> bool {
+    float xx1 = fmaxf(kb[k], bx1), yy1 = fmaxf(kb[md + k], by1);
+    float xx2 = fminf(kb[2 * md + k], bx2), yy2 = fminf(kb[3 * md + k], by2);
+    float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+    float inter = iw * ih;
+    float ovr = inter / (kb[4 * md + k] + area - inter);
+    return ovr > a.iou;
+  };
+  for (unsigned base = 0; base < K; base += NMS_THREADS) {
+    const int nk0 = s_nkept;            // kept before this round
+    __syncthreads();                    // everyone has read it before wave 0's turn may change it -> uniform
+    if (nk0 >= md) break;
+    unsigned idx = base + tid;
+    bool valid = idx < K;
+    u64 key = valid ? sbuf[idx] : KEY_NONE;
+    unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
+    int an = valid ? (int)(cand / (unsigned)a.nc) : 0, cls = valid ? (int)(cand % (unsigned)a.nc) : 0;
+    float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
+    float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
+    float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
+    float bx1 = x1 + off, by1 = y1 + off, bx2 = x2 + off, by2 = y2 + off;
+    float area = (bx2 - bx1) * (by2 - by1);
+    bool alive = valid;
+    for (int k = 0; k < nk0; ++k)
+      if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
+    for (int wv = 0; wv < NMS_THREADS / 64; ++wv) {
+      if (wave == wv) {
+        int nkept = s_nkept;
+        for (int k = nk0; k < nkept; ++k)
+          if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
+        u64 mask = __ballot(alive);
+        while (mask && nkept < md) {
+          int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
+          if (lane == i) {
+            kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
+            kidx[nkept] = idx;                    // its output row is written after the scan, in parallel
+            alive = false;
+          }
+          // lane i's LDS write must be ordered before the other lanes' reads: wavefront-scope fence for the compiler, the LDS pipe
+          // itself completes a wave's accesses in order; then a broadcast read replaces five shuffles
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (alive && lane > i && suppressed_by(nkept, bx1, by1, bx2, by2, area)) alive = false;
+          ++nkept;
+          mask = __ballot(alive);
+        }
+        if (lane == 0) s_nkept = nkept;
       }
       __syncthreads();
+      const int nk_now = s_nkept;
+      __syncthreads();                // read by all before the next wave's turn may change it -> uniform
+      if (nk_now >= md) break;
     }
   }
-
-  // ---- greedy suppression by wave 0
-  float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
-  if (tid < 64) {
-    const int lane = tid;
-    const int md = a.max_det;
-    int nkept = 0;
-    for (unsigned base = 0; base < K && nkept < md; base += 64) {
-      unsigned idx = base + lane;
-      bool valid = idx < K;
-      u64 key = valid ? sbuf[idx] : KEY_NONE;
-      unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
-      int an = valid ? (int)(cand / (unsigned)a.nc) : 0, cls = valid ? (int)(cand % (unsigned)a.nc) : 0;
-      float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
-      float score = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
-      float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
-      float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
-      float bx1 = x1 + off, by1 = y1 + off, bx2 = x2 + off, by2 = y2 + off;
-      float area = (bx2 - bx1) * (by2 - by1);
-      bool alive = valid;
-      for (int k = 0; k < nkept; ++k) {   // LDS broadcast reads
-        float xx1 = fmaxf(kb[k], bx1), yy1 = fmaxf(kb[md + k], by1);
-        float xx2 = fminf(kb[2 * md + k], bx2), yy2 = fminf(kb[3 * md + k], by2);
-        float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-        float inter = iw * ih;
-        float ovr = inter / (kb[4 * md + k] + area - inter);
-        if (ovr > a.iou) alive = false;
-      }
-      u64 mask = __ballot(alive);
-      while (mask && nkept < md) {
-        int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
-        float ix1 = __shfl(bx1, i), iy1 = __shfl(by1, i), ix2 = __shfl(bx2, i), iy2 = __shfl(by2, i), iar = __shfl(area, i);
-        if (lane == i) {
-          kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
-          float* o = a.out + ((long)img * md + nkept) * 6;
-          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = score; o[5] = (float)cls;
-          a.kept_anchor[(long)img * md + nkept] = an;
-          alive = false;
-        }
-        if (alive && lane > i) {
-          float xx1 = fmaxf(ix1, bx1), yy1 = fmaxf(iy1, by1), xx2 = fminf(ix2, bx2), yy2 = fminf(iy2, by2);
-          float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-          float inter = iw * ih;
-          float ovr = inter / (iar + area - inter);
-          if (ovr > a.iou) alive = false;
-        }
-        ++nkept;
-        mask = __ballot(alive);
-      }
-    }
-    if (lane == 0) a.counts[img] = nkept;
+  // output rows (x1,y1,x2,y2,conf,cls) + anchor index of the kept boxes, one thread per row
+  for (int t = tid; t < s_nkept; t += NMS_THREADS) {
+    const u64 key = sbuf[kidx[t]];
+    const unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
+    const int an = (int)(cand / (unsigned)a.nc), cls = (int)(cand % (unsigned)a.nc);
+    const float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
+    float* o = a.out + ((long)img * md + t) * 6;
+    o[0] = cx - w / 2.f; o[1] = cy - h / 2.f; o[2] = cx + w / 2.f; o[3] = cy + h / 2.f;
+    o[4] = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
+    o[5] = (float)cls;
+    a.kept_anchor[(long)img * md + t] = an;
   }
+  if (tid == 0) a.counts[img] = s_nkept;
+  if (tid == 0 && a.dbg) { unsigned long long T4 = wall_clock64(); gbuf[0] = T1 - T0; gbuf[1] = T2 - T1; gbuf[2] = T3 - T2; gbuf[3] = T4 - T3; gbuf[4] = K; }
 }
 
 static inline int next_pow2(int v) {
@@ -223,9 +322,10 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   if (n < 1 || nc < 1 || a < 1 || max_det < 1 || max_nms < 1 || (long)a * nc > 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: n=%d nc=%d a=%d max_det=%d", n, nc, a, max_det);
   multi_label = multi_label && nc > 1;   // ops.py:196
   if (ws_bytes < mgdt_nms_workspace_bytes(n, nc, a, multi_label, max_nms)) MGDT_FAIL(MGDT_WORKSPACE, "nms: workspace too small");
-  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)5 * max_det * sizeof(float);
+  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)6 * max_det * sizeof(float);
   if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: max_det=%d too large for the LDS kept list", max_det);
   NmsArgs g;
+  g.dbg = getenv("MGDT_NMS_DBG") != nullptr;
   g.pred = pred; g.n = n; g.nc = nc; g.A = a; g.conf = conf_thres; g.iou = iou_thres; g.classes = n_classes > 0 ? classes : nullptr;
   g.n_classes = n_classes; g.agnostic = agnostic; g.multi_label = multi_label; g.max_det = max_det; g.max_nms = max_nms;
   g.max_wh = max_wh; g.out = out; g.kept_anchor = kept_anchor; g.counts = counts; g.ws = (u64*)ws;
@@ -238,6 +338,7 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
     if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "nms: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     attr_lds = lds;
   }
+  if (!multi_label) nms_best_kernel<<<dim3(cdiv(a, 256), n), 256, 0, (hipStream_t)s>>>(g);
   nms_kernel<<<n, NMS_THREADS, lds, (hipStream_t)s>>>(g);
   MGDT_CHECK_LAUNCH("nms_fwd");
   return MGDT_OK;

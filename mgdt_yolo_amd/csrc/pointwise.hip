@@ -8,6 +8,53 @@
 
 static inline int grid_for(long work, int block = 256, int cap = 8192) { return (int)std::min<long>((work + block - 1) / block, cap); }
 
+// flat index -> (n, h, w, channel-vector q) with exact magic-number division (64-bit '/' and '%' cost ~100 instructions each)
+struct PixIdx { FastDiv fq, fw, fh; int Q, W, H; };
+static inline PixIdx make_pixidx(int H, int W, int Q) { return PixIdx{make_fastdiv((uint32_t)Q), make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)H), Q, W, H}; }
+__device__ __forceinline__ void decode_idx(uint32_t i, const PixIdx& d, int& n, int& h, int& w, int& q) {
+  uint32_t t = fdiv(i, d.fq);
+  q = (int)(i - t * d.Q);
+  uint32_t t2 = fdiv(t, d.fw);
+  w = (int)(t - t2 * d.W);
+  uint32_t t3 = fdiv(t2, d.fh);
+  h = (int)(t2 - t3 * d.H);
+  n = (int)t3;
+}
+// V consecutive channels <-> V floats (V = 4: 8/16 bytes, V = 8: 16/32 bytes per lane)
+template <typename T, int V> __device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; k += 4) {
+    f32x4 t = load4<T>(p + k);
+    v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
+  }
+}
+template <> __device__ __forceinline__ void ldv<bf16, 8>(const bf16* p, float (&v)[8]) {
+  bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+}
+template <typename T, int V> __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; k += 4) store4<T>(p + k, f32x4{v[k], v[k + 1], v[k + 2], v[k + 3]});
+}
+template <> __device__ __forceinline__ void stv<bf16, 8>(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t[k] = (bf16)v[k];
+  *(bf16x8*)p = t;
+}
+static inline bool vecN_ok(const mgdt_view* v, int dtype, int V) {
+  return v->sc == 1 && v->c % V == 0 && v->sw % V == 0 && v->sh % V == 0 && v->sn % V == 0 && ((uintptr_t)v->p % (V * dtype_size(dtype))) == 0;
+}
+// dispatch on dtype and vector width: bf16 views that allow it move 16 bytes per lane (V = 8), everything else V = 4
+#define MGDT_DISPATCH_TV(dtype, v8ok, ...)                                             \
+  do {                                                                                 \
+    if ((dtype) == MGDT_F32) { using T = float; constexpr int V = 4; __VA_ARGS__; }    \
+    else if ((dtype) == MGDT_BF16 && (v8ok)) { using T = bf16; constexpr int V = 8; __VA_ARGS__; } \
+    else if ((dtype) == MGDT_BF16) { using T = bf16; constexpr int V = 4; __VA_ARGS__; } \
+    else MGDT_FAIL(MGDT_BAD_DTYPE, "unsupported dtype %d", (int)(dtype));              \
+  } while (0)
+
 static inline bool vec4_ok(const mgdt_view* v, int dtype) {
   return v->sc == 1 && v->c % 4 == 0 && v->sw % 4 == 0 && v->sh % 4 == 0 && v->sn % 4 == 0 &&
          ((uintptr_t)v->p % (4 * dtype_size(dtype))) == 0;
@@ -33,12 +80,38 @@ __global__ void copy_kernel(const TX* __restrict__ x, long xsn, long xsh, long x
   }
 }
 
+template <typename TX, typename TY, int V>
+__global__ void copy_vec_kernel(const TX* __restrict__ x, long xsn, long xsh, long xsw, TY* __restrict__ y, long ysn, long ysh, long ysw,
+                                uint32_t total, PixIdx d) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, h, w, q;
+    decode_idx(i, d, n, h, w, q);
+    float v[V];
+    ldv<TX, V>(x + n * xsn + h * xsh + w * xsw + q * V, v);
+    stv<TY, V>(y + n * ysn + h * ysh + w * ysw + q * V, v);
+  }
+}
+
 extern "C" int mgdt_copy_fwd(const mgdt_view* x, int xdt, const mgdt_view* y, int ydt, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "copy: null/empty view");
   if (x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "copy: shape mismatch");
   long total = (long)x->n * x->h * x->w * x->c;
-  int g = grid_for(total);
   hipStream_t st = (hipStream_t)s;
+  if (total < 0x7fffffffL && vecN_ok(x, xdt, 8) && vecN_ok(y, ydt, 8)) {   // NHWC both sides: 8 channels per lane
+    PixIdx d = make_pixidx(x->h, x->w, x->c / 8);
+    uint32_t tv = (uint32_t)(total / 8);
+    int g = grid_for(tv);
+#define LV(TX, TY) copy_vec_kernel<TX, TY, 8><<<g, 256, 0, st>>>((const TX*)x->p, x->sn, x->sh, x->sw, (TY*)y->p, y->sn, y->sh, y->sw, tv, d)
+    if (xdt == MGDT_F32 && ydt == MGDT_F32) LV(float, float);
+    else if (xdt == MGDT_F32 && ydt == MGDT_BF16) LV(float, bf16);
+    else if (xdt == MGDT_BF16 && ydt == MGDT_F32) LV(bf16, float);
+    else if (xdt == MGDT_BF16 && ydt == MGDT_BF16) LV(bf16, bf16);
+    else MGDT_FAIL(MGDT_BAD_DTYPE, "copy: dtypes %d -> %d", xdt, ydt);
+#undef LV
+    MGDT_CHECK_LAUNCH("copy_fwd");
+    return MGDT_OK;
+  }
+  int g = grid_for(total);
 #define L(TX, TY) copy_kernel<TX, TY><<<g, 256, 0, st>>>((const TX*)x->p, x->sn, x->sh, x->sw, x->sc, (TY*)y->p, y->sn, y->sh, y->sw, y->sc, x->n, x->h, x->w, x->c)
   if (xdt == MGDT_F32 && ydt == MGDT_F32) L(float, float);
   else if (xdt == MGDT_F32 && ydt == MGDT_BF16) L(float, bf16);
@@ -157,21 +230,18 @@ extern "C" int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const 
   return MGDT_OK;
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void scale_channels_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, const float* __restrict__ attn,
-                                      T* __restrict__ y, long ysn, long ysh, long ysw, int N, int H, int W, int C) {
-  const int Q = C / 4;
-  long total = (long)N * H * W * Q;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int w = (int)(t % W);
-    t /= W;
-    int h = (int)(t % H);
-    int n = (int)(t / H);
-    f32x4 v = load4<T>(x + n * xsn + h * xsh + w * xsw + q * 4);
-    f32x4 a = *(const f32x4*)(attn + (long)n * C + q * 4);
-    store4<T>(y + n * ysn + h * ysh + w * ysw + q * 4, v * a);
+                                      T* __restrict__ y, long ysn, long ysh, long ysw, uint32_t total, int C, PixIdx d) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, h, w, q;
+    decode_idx(i, d, n, h, w, q);
+    float v[V], a[V];
+    ldv<T, V>(x + n * xsn + h * xsh + w * xsw + q * V, v);
+    ldv<float, V>(attn + (long)n * C + q * V, a);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] *= a[k];
+    stv<T, V>(y + n * ysn + h * ysh + w * ysw + q * V, v);
   }
 }
 
@@ -179,50 +249,60 @@ extern "C" int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, co
   if (!view_ok(x) || !view_ok(y) || !attn) MGDT_FAIL(MGDT_BAD_ARG, "scale_channels: null/empty argument");
   if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c)
     MGDT_FAIL(MGDT_BAD_SHAPE, "scale_channels: views must be matching NHWC, c%%4==0");
-  long total = (long)x->n * x->h * x->w * (x->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (scale_channels_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>(
-                                 (const T*)x->p, x->sn, x->sh, x->sw, attn, (T*)y->p, y->sn, y->sh, y->sw, x->n, x->h, x->w, x->c)));
+  long tot = (long)x->n * x->h * x->w * x->c;
+  if (tot >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "scale_channels: too large");
+  MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8), {
+    PixIdx d = make_pixidx(x->h, x->w, x->c / V);
+    uint32_t total = (uint32_t)(tot / V);
+    scale_channels_kernel<T, V><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, attn, (T*)y->p, y->sn, y->sh, y->sw, total, x->c, d);
+  });
   MGDT_CHECK_LAUNCH("scale_channels_fwd");
   return MGDT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ SPPF pools
-// maxpool5 applied 1x/2x/3x == max over (5,9,13)-windows with -inf padding; one pass over x writes all three.
-template <typename T>
-__global__ void sppf_pool_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y1, long s1n, long s1h,
-                                 long s1w, T* __restrict__ y2, long s2n, long s2h, long s2w, T* __restrict__ y3, long s3n,
-                                 long s3h, long s3w, int N, int H, int W, int C) {
-  const int Q = C / 4;
-  long total = (long)N * H * W * Q;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int w = (int)(t % W);
-    t /= W;
-    int h = (int)(t % H);
-    int n = (int)(t / H);
-    f32x4 m5 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}, m9 = m5, m13 = m5;
-    for (int dy = -6; dy <= 6; ++dy) {
-      int yy = h + dy;
-      if (yy < 0 || yy >= H) continue;
-      int ady = dy < 0 ? -dy : dy;
-      for (int dx = -6; dx <= 6; ++dx) {
-        int xx = w + dx;
-        if (xx < 0 || xx >= W) continue;
-        int adx = dx < 0 ? -dx : dx;
-        int rad = ady > adx ? ady : adx;
-        f32x4 v = load4<T>(x + n * xsn + yy * xsh + xx * xsw + q * 4);
+// One workgroup = one image x 8 channels: the whole HxW plane (20x20 at 640^2) sits in LDS as fp32 and MaxPool2d(5,1,2)
+// is applied three times as separable row / column 5-tap max passes (-inf padding), writing y1, y2, y3 after each.
+template <typename T, int SPPF_CG>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y1, long s1n,
+                                                        long s1h, long s1w, T* __restrict__ y2, long s2n, long s2h, long s2w,
+                                                        T* __restrict__ y3, long s3n, long s3h, long s3w, int H, int W) {
+  extern __shared__ float sm[];
+  const int n = blockIdx.x, c0 = blockIdx.y * SPPF_CG, HW = H * W;
+  float* A = sm;                  // [HW][SPPF_CG]
+  float* Bf = sm + HW * SPPF_CG;
+  constexpr int QN = SPPF_CG / 4;
+  for (int i = threadIdx.x; i < HW * QN; i += 256) {   // 4 channels per lane
+    int p = i / QN, qq = (i % QN) * 4;
+    f32x4 v = load4<T>(x + n * xsn + (p / W) * xsh + (p % W) * xsw + c0 + qq);
+    *(f32x4*)(A + p * SPPF_CG + qq) = v;
+  }
+  __syncthreads();
+  T* outs[3] = {y1, y2, y3};
+  const long on[3] = {s1n, s2n, s3n}, oh[3] = {s1h, s2h, s3h}, ow[3] = {s1w, s2w, s3w};
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = threadIdx.x; i < HW * SPPF_CG; i += 256) {   // rows: A -> Bf
+      int c = i % SPPF_CG, p = i / SPPF_CG, w = p % W, rowb = p - w;
+      float m = A[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          m13[j] = fmaxf(m13[j], v[j]);
-          if (rad <= 4) m9[j] = fmaxf(m9[j], v[j]);
-          if (rad <= 2) m5[j] = fmaxf(m5[j], v[j]);
-        }
-      }
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(w + d) < (unsigned)W) m = fmaxf(m, A[(rowb + w + d) * SPPF_CG + c]);
+      Bf[i] = m;
     }
-    store4<T>(y1 + n * s1n + h * s1h + w * s1w + q * 4, m5);
-    store4<T>(y2 + n * s2n + h * s2h + w * s2w + q * 4, m9);
-    store4<T>(y3 + n * s3n + h * s3h + w * s3w + q * 4, m13);
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW * SPPF_CG; i += 256) {   // columns: Bf -> A
+      int c = i % SPPF_CG, p = i / SPPF_CG, h = p / W, w = p - h * W;
+      float m = Bf[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(h + d) < (unsigned)H) m = fmaxf(m, Bf[((h + d) * W + w) * SPPF_CG + c]);
+      A[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW * QN; i += 256) {
+      int p = i / QN, qq = (i % QN) * 4;
+      store4<T>(outs[pass] + n * on[pass] + (p / W) * oh[pass] + (p % W) * ow[pass] + c0 + qq, *(const f32x4*)(A + p * SPPF_CG + qq));
+    }
   }
 }
 
@@ -232,45 +312,58 @@ extern "C" int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const
   for (const mgdt_view* v : {x, y1, y2, y3})
     if (!vec4_ok(v, dtype) || v->n != x->n || v->h != x->h || v->w != x->w || v->c != x->c)
       MGDT_FAIL(MGDT_BAD_SHAPE, "sppf_pool: views must be matching NHWC, c%%4==0");
-  long total = (long)x->n * x->h * x->w * (x->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (sppf_pool_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>(
-                                 (const T*)x->p, x->sn, x->sh, x->sw, (T*)y1->p, y1->sn, y1->sh, y1->sw, (T*)y2->p, y2->sn, y2->sh,
-                                 y2->sw, (T*)y3->p, y3->sn, y3->sh, y3->sw, x->n, x->h, x->w, x->c)));
+  const long hw = (long)x->h * x->w;
+  const int cg = (x->c % 8 == 0 && hw * 8 * 2 * 4 <= 64 * 1024) ? 8 : 4;          // channels per workgroup so the plane fits 64 KiB of LDS
+  size_t lds = (size_t)hw * cg * 2 * sizeof(float);
+  if (lds > 64 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "sppf_pool: the %dx%d map does not fit the LDS plane kernel (h*w <= 2048)", x->h, x->w);
+  dim3 grid(x->n, x->c / cg);
+#define SPPF_L(CG) MGDT_DISPATCH_DTYPE(dtype, (sppf_pool_kernel<T, CG><<<grid, 256, lds, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, (T*)y1->p, y1->sn, y1->sh, y1->sw, \
+                                                 (T*)y2->p, y2->sn, y2->sh, y2->sw, (T*)y3->p, y3->sn, y3->sh, y3->sw, x->h, x->w)))
+  if (cg == 8) SPPF_L(8); else SPPF_L(4);
+#undef SPPF_L
   MGDT_CHECK_LAUNCH("sppf_pool_fwd");
   return MGDT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ resamplers
-template <typename T>
+template <typename T, int V>
 __global__ void avgpool_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, int H, int W, T* __restrict__ y, long ysn,
-                               long ysh, long ysw, int N, int Ho, int Wo, int C) {
-  const int Q = C / 4;
-  long total = (long)N * Ho * Wo * Q;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int ox = (int)(t % Wo);
-    t /= Wo;
-    int oy = (int)(t % Ho);
-    int n = (int)(t / Ho);
-    int y0 = bin_start(oy, H, Ho), y1 = bin_end(oy, H, Ho), x0 = bin_start(ox, W, Wo), x1 = bin_end(ox, W, Wo);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                               long ysh, long ysw, uint32_t total, PixIdx d) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, oy, ox, q;
+    decode_idx(i, d, n, oy, ox, q);
+    int y0 = bin_start(oy, H, d.H), y1 = bin_end(oy, H, d.H), x0 = bin_start(ox, W, d.W), x1 = bin_end(ox, W, d.W);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
     for (int yy = y0; yy < y1; ++yy)
-      for (int xx = x0; xx < x1; ++xx) acc += load4<T>(x + n * xsn + yy * xsh + xx * xsw + q * 4);
+      for (int xx = x0; xx < x1; ++xx) {
+        float v[V];
+        ldv<T, V>(x + n * xsn + yy * xsh + xx * xsw + q * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += v[k];
+      }
     float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
-    store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, acc * inv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] *= inv;
+    stv<T, V>(y + n * ysn + oy * ysh + ox * ysw + q * V, acc);
   }
 }
 
-extern "C" int mgdt_adaptive_avgpool_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "avgpool: null/empty view");
-  if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "avgpool: NHWC views, c%%4==0, same n/c");
-  long total = (long)y->n * y->h * y->w * (y->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (avgpool_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, x->h, x->w,
-                                                                                        (T*)y->p, y->sn, y->sh, y->sw, y->n, y->h, y->w, y->c)));
-  MGDT_CHECK_LAUNCH("adaptive_avgpool_fwd");
-  return MGDT_OK;
-}
+#define RESAMPLE_ENTRY(fname, kern, label)                                                                                              \
+  extern "C" int fname(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {                                             \
+    if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, label ": null/empty view");                                                \
+    if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, label ": NHWC views, c%%4==0, same n/c"); \
+    long tot = (long)y->n * y->h * y->w * y->c;                                                                                        \
+    if (tot >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, label ": too large");                                                            \
+    MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8), {                                                            \
+      PixIdx d = make_pixidx(y->h, y->w, y->c / V);                                                                                    \
+      uint32_t total = (uint32_t)(tot / V);                                                                                            \
+      kern<T, V><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, x->h, x->w, (T*)y->p, y->sn, y->sh, y->sw, total, d); \
+    });                                                                                                                                \
+    MGDT_CHECK_LAUNCH(label);                                                                                                          \
+    return MGDT_OK;                                                                                                                    \
+  }
 
 // F.interpolate(bilinear, align_corners=False): src = max(0, (dst+0.5)*in/out - 0.5), upper neighbour clamped
 struct Lerp { int i0, i1; float l0, l1; };
@@ -285,123 +378,108 @@ __device__ __forceinline__ Lerp lerp_of(int o, int isz, int osz) {
   return Lerp{i0, i1, 1.f - l1, l1};
 }
 
-template <typename T>
-__device__ __forceinline__ f32x4 bilerp(const T* x, long sh, long sw, Lerp ly, Lerp lx) {
-  f32x4 v00 = load4<T>(x + ly.i0 * sh + lx.i0 * sw), v01 = load4<T>(x + ly.i0 * sh + lx.i1 * sw);
-  f32x4 v10 = load4<T>(x + ly.i1 * sh + lx.i0 * sw), v11 = load4<T>(x + ly.i1 * sh + lx.i1 * sw);
-  return (v00 * lx.l0 + v01 * lx.l1) * ly.l0 + (v10 * lx.l0 + v11 * lx.l1) * ly.l1;
+template <typename T, int V, bool HSIG>
+__device__ __forceinline__ void bilerp(const T* x, long sh, long sw, Lerp ly, Lerp lx, float (&o)[V]) {
+  float v00[V], v01[V], v10[V], v11[V];
+  ldv<T, V>(x + ly.i0 * sh + lx.i0 * sw, v00);
+  ldv<T, V>(x + ly.i0 * sh + lx.i1 * sw, v01);
+  ldv<T, V>(x + ly.i1 * sh + lx.i0 * sw, v10);
+  ldv<T, V>(x + ly.i1 * sh + lx.i1 * sw, v11);
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    if (HSIG) {   // h_sigmoid BEFORE the interpolation (block.py:393)
+      v00[k] = fminf(fmaxf(v00[k] + 3.f, 0.f), 6.f) / 6.f; v01[k] = fminf(fmaxf(v01[k] + 3.f, 0.f), 6.f) / 6.f;
+      v10[k] = fminf(fmaxf(v10[k] + 3.f, 0.f), 6.f) / 6.f; v11[k] = fminf(fmaxf(v11[k] + 3.f, 0.f), 6.f) / 6.f;
+    }
+    o[k] = (v00[k] * lx.l0 + v01[k] * lx.l1) * ly.l0 + (v10[k] * lx.l0 + v11[k] * lx.l1) * ly.l1;
+  }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void bilinear_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, int H, int W, T* __restrict__ y, long ysn,
-                                long ysh, long ysw, int N, int Ho, int Wo, int C) {
-  const int Q = C / 4;
-  long total = (long)N * Ho * Wo * Q;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int ox = (int)(t % Wo);
-    t /= Wo;
-    int oy = (int)(t % Ho);
-    int n = (int)(t / Ho);
-    store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, bilerp<T>(x + n * xsn + q * 4, xsh, xsw, lerp_of(oy, H, Ho), lerp_of(ox, W, Wo)));
+                                long ysh, long ysw, uint32_t total, PixIdx d) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, oy, ox, q;
+    decode_idx(i, d, n, oy, ox, q);
+    float o[V];
+    bilerp<T, V, false>(x + n * xsn + q * V, xsh, xsw, lerp_of(oy, H, d.H), lerp_of(ox, W, d.W), o);
+    stv<T, V>(y + n * ysn + oy * ysh + ox * ysw + q * V, o);
   }
 }
 
-extern "C" int mgdt_bilinear_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "bilinear: null/empty view");
-  if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "bilinear: NHWC views, c%%4==0, same n/c");
-  long total = (long)y->n * y->h * y->w * (y->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (bilinear_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, x->h, x->w,
-                                                                                         (T*)y->p, y->sn, y->sh, y->sw, y->n, y->h, y->w, y->c)));
-  MGDT_CHECK_LAUNCH("bilinear_fwd");
-  return MGDT_OK;
-}
-
-template <typename T>
+template <typename T, int V>
 __global__ void nearest_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, int H, int W, T* __restrict__ y, long ysn,
-                               long ysh, long ysw, int N, int Ho, int Wo, int C) {
-  const int Q = C / 4;
-  long total = (long)N * Ho * Wo * Q;
-  const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int ox = (int)(t % Wo);
-    t /= Wo;
-    int oy = (int)(t % Ho);
-    int n = (int)(t / Ho);
+                               long ysh, long ysw, uint32_t total, PixIdx d) {
+  const float sy = (float)H / (float)d.H, sx = (float)W / (float)d.W;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, oy, ox, q;
+    decode_idx(i, d, n, oy, ox, q);
     int iy = min((int)floorf((float)oy * sy), H - 1), ix = min((int)floorf((float)ox * sx), W - 1);
-    store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, load4<T>(x + n * xsn + iy * xsh + ix * xsw + q * 4));
+    float v[V];
+    ldv<T, V>(x + n * xsn + iy * xsh + ix * xsw + q * V, v);
+    stv<T, V>(y + n * ysn + oy * ysh + ox * ysw + q * V, v);
   }
 }
 
-extern "C" int mgdt_nearest_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "nearest: null/empty view");
-  if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "nearest: NHWC views, c%%4==0, same n/c");
-  long total = (long)y->n * y->h * y->w * (y->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (nearest_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, x->h, x->w,
-                                                                                        (T*)y->p, y->sn, y->sh, y->sw, y->n, y->h, y->w, y->c)));
-  MGDT_CHECK_LAUNCH("nearest_fwd");
-  return MGDT_OK;
-}
+RESAMPLE_ENTRY(mgdt_adaptive_avgpool_fwd, avgpool_kernel, "adaptive_avgpool")
+RESAMPLE_ENTRY(mgdt_bilinear_fwd, bilinear_kernel, "bilinear")
+RESAMPLE_ENTRY(mgdt_nearest_fwd, nearest_kernel, "nearest")
 
 // ------------------------------------------------------------------------------------------------ Injection tail
-template <typename T>
+template <typename T, int V>
 __global__ void inject_kernel(const T* __restrict__ loc, long lsn, long lsh, long lsw, const T* __restrict__ ga, long asn, long ash,
                               long asw, const T* __restrict__ gf, long fsn, long fsh, long fsw, int Hg, int Wg, T* __restrict__ y,
-                              long ysn, long ysh, long ysw, int N, int H, int W, int C, int use_pool) {
-  const int Q = C / 4;
-  long total = (long)N * H * W * Q;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int q = (int)(i % Q);
-    long t = i / Q;
-    int ox = (int)(t % W);
-    t /= W;
-    int oy = (int)(t % H);
-    int n = (int)(t / H);
-    f32x4 l = load4<T>(loc + n * lsn + oy * lsh + ox * lsw + q * 4);
-    f32x4 sig, feat;
+                              long ysn, long ysh, long ysw, uint32_t total, PixIdx d, int use_pool) {
+  const int H = d.H, W = d.W;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int n, oy, ox, q;
+    decode_idx(i, d, n, oy, ox, q);
+    float l[V], sig[V], feat[V];
+    ldv<T, V>(loc + n * lsn + oy * lsh + ox * lsw + q * V, l);
     if (use_pool) {
       int y0 = bin_start(oy, Hg, H), y1 = bin_end(oy, Hg, H), x0 = bin_start(ox, Wg, W), x1 = bin_end(ox, Wg, W);
-      sig = f32x4{0.f, 0.f, 0.f, 0.f};
-      feat = sig;
+#pragma unroll
+      for (int k = 0; k < V; ++k) sig[k] = feat[k] = 0.f;
       for (int yy = y0; yy < y1; ++yy)
         for (int xx = x0; xx < x1; ++xx) {
-          sig += load4<T>(ga + n * asn + yy * ash + xx * asw + q * 4);
-          feat += load4<T>(gf + n * fsn + yy * fsh + xx * fsw + q * 4);
+          float a[V], f[V];
+          ldv<T, V>(ga + n * asn + yy * ash + xx * asw + q * V, a);
+          ldv<T, V>(gf + n * fsn + yy * fsh + xx * fsw + q * V, f);
+#pragma unroll
+          for (int k = 0; k < V; ++k) { sig[k] += a[k]; feat[k] += f[k]; }
         }
       float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
-      sig *= inv;
-      feat *= inv;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { sig[k] *= inv; feat[k] *= inv; }
     } else {
       Lerp ly = lerp_of(oy, Hg, H), lx = lerp_of(ox, Wg, W);
-      const T* a = ga + n * asn + q * 4;
-      f32x4 h[4] = {load4<T>(a + ly.i0 * ash + lx.i0 * asw), load4<T>(a + ly.i0 * ash + lx.i1 * asw),
-                    load4<T>(a + ly.i1 * ash + lx.i0 * asw), load4<T>(a + ly.i1 * ash + lx.i1 * asw)};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          h[k][j] = fminf(fmaxf(h[k][j] + 3.f, 0.f), 6.f) / 6.f;   // h_sigmoid BEFORE the interpolation (block.py:393)
-      sig = (h[0] * lx.l0 + h[1] * lx.l1) * ly.l0 + (h[2] * lx.l0 + h[3] * lx.l1) * ly.l1;
-      feat = bilerp<T>(gf + n * fsn + q * 4, fsh, fsw, ly, lx);
+      bilerp<T, V, true>(ga + n * asn + q * V, ash, asw, ly, lx, sig);
+      bilerp<T, V, false>(gf + n * fsn + q * V, fsh, fsw, ly, lx, feat);
     }
-    store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, l * sig + feat);
+#pragma unroll
+    for (int k = 0; k < V; ++k) l[k] = l[k] * sig[k] + feat[k];
+    stv<T, V>(y + n * ysn + oy * ysh + ox * ysw + q * V, l);
   }
 }
 
 extern "C" int mgdt_inject_fwd(const mgdt_view* local, const mgdt_view* ga, const mgdt_view* gf, const mgdt_view* y, int dtype,
                                mgdt_stream s) {
   if (!view_ok(local) || !view_ok(ga) || !view_ok(gf) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "inject: null/empty view");
-  for (const mgdt_view* v : {local, ga, gf, y})
+  bool v8 = true;
+  for (const mgdt_view* v : {local, ga, gf, y}) {
     if (!vec4_ok(v, dtype) || v->n != y->n || v->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "inject: NHWC views, c%%4==0, same n/c");
+    v8 = v8 && vecN_ok(v, dtype, 8);
+  }
   if (local->h != y->h || local->w != y->w || ga->h != gf->h || ga->w != gf->w) MGDT_FAIL(MGDT_BAD_SHAPE, "inject: spatial mismatch");
   int use_pool = local->h < ga->h;
-  long total = (long)y->n * y->h * y->w * (y->c / 4);
-  MGDT_DISPATCH_DTYPE(dtype, (inject_kernel<T><<<grid_for(total), 256, 0, (hipStream_t)s>>>(
-                                 (const T*)local->p, local->sn, local->sh, local->sw, (const T*)ga->p, ga->sn, ga->sh, ga->sw, (const T*)gf->p,
-                                 gf->sn, gf->sh, gf->sw, ga->h, ga->w, (T*)y->p, y->sn, y->sh, y->sw, y->n, y->h, y->w, y->c, use_pool)));
+  long tot = (long)y->n * y->h * y->w * y->c;
+  if (tot >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "inject: too large");
+  MGDT_DISPATCH_TV(dtype, v8, {
+    PixIdx d = make_pixidx(y->h, y->w, y->c / V);
+    uint32_t total = (uint32_t)(tot / V);
+    inject_kernel<T, V><<<grid_for(total), 256, 0, (hipStream_t)s>>>((const T*)local->p, local->sn, local->sh, local->sw, (const T*)ga->p, ga->sn, ga->sh, ga->sw,
+                                                                     (const T*)gf->p, gf->sn, gf->sh, gf->sw, ga->h, ga->w, (T*)y->p, y->sn, y->sh, y->sw, total, d, use_pool);
+  });
   MGDT_CHECK_LAUNCH("inject_fwd");
   return MGDT_OK;
 }
@@ -477,18 +555,22 @@ extern "C" int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const 
 }
 
 // ------------------------------------------------------------------------------------------------ GRN statistics
-// ws[n][c] = sum_{h,w} t^2 ; then scale[n][c] = gamma[c] * sqrt(ws) / (mean_c sqrt(ws) + 1e-6) + 1
+// ws[n][split][c] = partial sum_{h,w in band} t^2 (fixed order -> deterministic); then
+// scale[n][c] = gamma[c] * sqrt(sum) / (mean_c sqrt(sum) + 1e-6) + 1
+#define GRN_SPLITS MGDT_GRN_SPLITS
 template <typename T>
 __global__ __launch_bounds__(256) void grn_sumsq_kernel(const T* __restrict__ t, long sn, long sh, long sw, int H, int W, int C,
                                                         float* __restrict__ ws) {
-  const int n = blockIdx.x, q0 = blockIdx.y * 16;   // 16 quads = 64 channels per block
+  const int n = blockIdx.x, q0 = blockIdx.y * 16, split = blockIdx.z;   // 16 quads = 64 channels per block
   const int ql = threadIdx.x & 15, pr = threadIdx.x >> 4;
   const int q = q0 + ql;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   if (q * 4 < C) {
-    const long npix = (long)H * W;
-    for (long p = pr; p < npix; p += 16) {
-      f32x4 v = load4<T>(t + n * sn + (p / W) * sh + (p % W) * sw + q * 4);
+    const int npix = H * W;
+    const int p0 = (int)((long)split * npix / GRN_SPLITS), p1 = (int)((long)(split + 1) * npix / GRN_SPLITS);
+    for (int p = p0 + pr; p < p1; p += 16) {
+      int yy = p / W, xx = p - yy * W;
+      f32x4 v = load4<T>(t + n * sn + yy * sh + xx * sw + q * 4);
       acc += v * v;
     }
   }
@@ -501,16 +583,22 @@ __global__ __launch_bounds__(256) void grn_sumsq_kernel(const T* __restrict__ t,
     float sum = 0.f;
     for (int r = 0; r < 16; ++r) sum += red[j][r * 16 + qq];
     int c = (q0 + qq) * 4 + j;
-    if (c < C) ws[(long)n * C + c] = sum;
+    if (c < C) ws[((long)n * GRN_SPLITS + split) * C + c] = sum;
   }
 }
 
 __global__ __launch_bounds__(256) void grn_scale_kernel(const float* __restrict__ ws, const float* __restrict__ gamma, int C,
                                                         float* __restrict__ scale) {
   const int n = blockIdx.x;
+  extern __shared__ float gx[];   // [C]
   __shared__ float red[256];
   float part = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) part += sqrtf(ws[(long)n * C + c]);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sum = 0.f;
+    for (int sp = 0; sp < GRN_SPLITS; ++sp) sum += ws[((long)n * GRN_SPLITS + sp) * C + c];
+    gx[c] = sqrtf(sum);
+    part += gx[c];
+  }
   red[threadIdx.x] = part;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -518,15 +606,15 @@ __global__ __launch_bounds__(256) void grn_scale_kernel(const float* __restrict_
     __syncthreads();
   }
   float mean = red[0] / (float)C;
-  for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = gamma[c] * (sqrtf(ws[(long)n * C + c]) / (mean + 1e-6f)) + 1.f;
+  for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = gamma[c] * (gx[c] / (mean + 1e-6f)) + 1.f;
 }
 
 extern "C" int mgdt_grn_stats_fwd(const mgdt_view* t, const float* gamma, float* ws, float* scale, int dtype, mgdt_stream s) {
   if (!view_ok(t) || !gamma || !ws || !scale) MGDT_FAIL(MGDT_BAD_ARG, "grn_stats: null/empty argument");
-  if (!vec4_ok(t, dtype)) MGDT_FAIL(MGDT_BAD_SHAPE, "grn_stats: NHWC view, c%%4==0");
-  dim3 grid(t->n, cdiv(t->c, 64));
+  if (!vec4_ok(t, dtype) || t->c > 8192) MGDT_FAIL(MGDT_BAD_SHAPE, "grn_stats: NHWC view, c%%4==0, c<=8192");
+  dim3 grid(t->n, cdiv(t->c, 64), GRN_SPLITS);
   MGDT_DISPATCH_DTYPE(dtype, (grn_sumsq_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>((const T*)t->p, t->sn, t->sh, t->sw, t->h, t->w, t->c, ws)));
-  grn_scale_kernel<<<t->n, 256, 0, (hipStream_t)s>>>(ws, gamma, t->c, scale);
+  grn_scale_kernel<<<t->n, 256, t->c * sizeof(float), (hipStream_t)s>>>(ws, gamma, t->c, scale);
   MGDT_CHECK_LAUNCH("grn_stats_fwd");
   return MGDT_OK;
 }
@@ -566,11 +654,69 @@ __global__ void detect_decode_kernel(const T* __restrict__ f, long sn, long sh, 
   }
 }
 
+// LDS-transposing variant: a block takes 128 consecutive anchors, loads their NHWC rows coalesced into an fp32 tile [128][no+1]
+// (odd row stride -> conflict-free column reads), then writes y[n][ch][a] with consecutive lanes = consecutive anchors.
+#define DEC_A 128
+template <typename T>
+__global__ __launch_bounds__(256) void detect_decode_tile_kernel(const T* __restrict__ f, long sn, long sh, long sw, int H, int W, int R,
+                                                                 int nc, float stride, int a_off, int a_total, float* __restrict__ y) {
+  extern __shared__ float tile[];
+  const int no = 4 * R + nc, ld = no + 1, HW = H * W;
+  const int n = blockIdx.y, a0 = blockIdx.x * DEC_A;
+  const int na = min(DEC_A, HW - a0), Q = no / 4;
+  for (int i = threadIdx.x; i < na * Q; i += 256) {
+    int al = i / Q, q = i - al * Q, a = a0 + al;
+    int oy = a / W, ox = a - oy * W;
+    f32x4 v = load4<T>(f + n * sn + oy * sh + ox * sw + q * 4);
+    float* d = tile + al * ld + q * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  float* yo = y + (long)n * (4 + nc) * a_total + a_off + a0;
+  if (threadIdx.x < na) {   // box: DFL softmax-expectation per side, dist2bbox, stride
+    const int al = threadIdx.x, a = a0 + al;
+    const float* p = tile + al * ld;
+    float dd[4];
+#pragma unroll
+    for (int side = 0; side < 4; ++side) {
+      float mx = -INFINITY;
+      for (int k = 0; k < R; ++k) mx = fmaxf(mx, p[side * R + k]);
+      float den = 0.f, num = 0.f;
+      for (int k = 0; k < R; ++k) {
+        float e = expf(p[side * R + k] - mx);
+        den += e;
+        num += e * (float)k;
+      }
+      dd[side] = num / den;
+    }
+    int oy = a / W, ox = a - oy * W;
+    float ax = (float)ox + 0.5f, ay = (float)oy + 0.5f;
+    float x1 = ax - dd[0], y1 = ay - dd[1], x2 = ax + dd[2], y2 = ay + dd[3];
+    yo[al] = (x1 + x2) / 2.f * stride;
+    yo[(long)a_total + al] = (y1 + y2) / 2.f * stride;
+    yo[2L * a_total + al] = (x2 - x1) * stride;
+    yo[3L * a_total + al] = (y2 - y1) * stride;
+  }
+  for (int i = threadIdx.x; i < nc * DEC_A; i += 256) {   // cls: sigmoid, lanes = consecutive anchors of one channel plane
+    int c = i / DEC_A, al = i - c * DEC_A;
+    if (al < na) yo[(long)(4 + c) * a_total + al] = 1.f / (1.f + expf(-tile[al * ld + 4 * R + c]));
+  }
+}
+
 extern "C" int mgdt_detect_decode_fwd(const mgdt_view* feat, int reg_max, int nc, float stride, int a_off, int a_total, float* y,
                                       int dtype, mgdt_stream s) {
   if (!view_ok(feat) || !y) MGDT_FAIL(MGDT_BAD_ARG, "detect_decode: null/empty argument");
   if (feat->sc != 1 || feat->c != 4 * reg_max + nc || reg_max < 1 || a_off < 0 || a_off + feat->h * feat->w > a_total)
     MGDT_FAIL(MGDT_BAD_SHAPE, "detect_decode: c=%d reg_max=%d nc=%d a_off=%d a_total=%d", feat->c, reg_max, nc, a_off, a_total);
+  const int no = feat->c;
+  size_t lds = (size_t)DEC_A * (no + 1) * sizeof(float);
+  if (vec4_ok(feat, dtype) && lds <= 64 * 1024) {
+    dim3 grid(cdiv((long)feat->h * feat->w, DEC_A), feat->n);
+    MGDT_DISPATCH_DTYPE(dtype, (detect_decode_tile_kernel<T><<<grid, 256, lds, (hipStream_t)s>>>((const T*)feat->p, feat->sn, feat->sh, feat->sw, feat->h, feat->w,
+                                                                                                 reg_max, nc, stride, a_off, a_total, y)));
+    MGDT_CHECK_LAUNCH("detect_decode_fwd");
+    return MGDT_OK;
+  }
   long total = (long)feat->n * feat->h * feat->w;
   MGDT_DISPATCH_DTYPE(dtype, (detect_decode_kernel<T><<<grid_for(total, 64), 64, 0, (hipStream_t)s>>>((const T*)feat->p, feat->sn, feat->sh, feat->sw, feat->n,
                                                                                                 feat->h, feat->w, reg_max, nc, stride, a_off, a_total, y)));

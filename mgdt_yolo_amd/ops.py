@@ -214,7 +214,7 @@ def dwconv7_ln(x, dw_w49c, dw_b, ln_w, ln_b, eps, out=None):
 def grn_scale(t, gamma):
     """scale[n,c] = gamma[c]*Nx[n,c] + 1 (fp32) for the GRN-folded pwconv2."""
     b, c = t.shape[:2]
-    ws = torch.empty(b, c, dtype=torch.float32, device=t.device)
+    ws = torch.empty(b * L.GRN_SPLITS * c, dtype=torch.float32, device=t.device)
     sc = torch.empty(b, c, dtype=torch.float32, device=t.device)
     _launch('grn_stats_fwd', 'mgdt_grn_stats_fwd', vp(t), ptr(gamma), ptr(ws), ptr(sc), dtype_code(t.dtype), stream())
     return sc
