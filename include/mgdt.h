@@ -121,6 +121,24 @@ int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, floa
                  int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
                  int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s);
 
+/* ---- v8DetectionLoss: assigner + BCE/CIoU/DFL + gradient w.r.t. the head maps -----------------------------------------
+ * yolo/utils/loss.py:108-208 (v8DetectionLoss.__call__, BboxLoss :56-89), yolo/utils/tal.py:56-353
+ * (HeuristicPositiveSampleAssigner_v1 -> TaskAlignedAssigner, topk 10, alpha = 0.5*(100 - call_count/161)/100, beta 8),
+ * yolo/utils/metrics.py:75-128 (CIoU).  feats[l]: raw head map of level l, NHWC view (B, 4R+nc, H, W); gt: fp32
+ * [B][n_gt][5] = (cls, x1, y1, x2, y2) in pixels, zero rows = padding (what loss.py:132-148 `preprocess` builds).
+ * out5 (device) = {loss*B, box, cls, dfl (gains applied), target_scores_sum}.  Optional device outputs (may be NULL):
+ * fg_out uint8 [B][A], gt_idx_out int32 [B][A], tscore_out fp32 [B][A] (the normalised target score of the assigned class).
+ * Top-k ties: lower anchor index first.  n_gt == 0: all-background targets (the reference raises here, tal.py:102-108).
+ * bwd: grads[l] = gscale * d(loss*B)/d feats[l]; call after fwd with the same ws / out5 / arguments.                    */
+size_t mgdt_detect_loss_workspace_bytes(int b, int a_total, int n_gt);
+int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
+                         const float* gt, int n_gt, int call_count, float gain_box, float gain_cls, float gain_dfl,
+                         float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
+                         size_t ws_bytes, int dtype, mgdt_stream s);
+int mgdt_detect_loss_bwd(const mgdt_view* const* feats, const mgdt_view* const* grads, const float* strides, int n_levels,
+                         int reg_max, int nc, const float* gt, int n_gt, float gain_box, float gain_cls, float gain_dfl,
+                         float gscale, const float* out5, void* ws, size_t ws_bytes, int dtype, mgdt_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,9 @@ PROTOTYPES = {
     'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
     'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),
+    'mgdt_detect_loss_workspace_bytes': (_sz, [_i, _i, _i]),
+    'mgdt_detect_loss_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    'mgdt_detect_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

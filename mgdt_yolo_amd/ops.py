@@ -254,3 +254,56 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, ma
                              int(bool(agnostic)), ml, max_det, max_nms, float(max_wh), ptr(out), ptr(kept), ptr(counts), ptr(ws),
                              ws_bytes, stream())
     return out, kept, counts
+
+
+# ------------------------------------------------------------------ detection loss (assigner + BCE/CIoU/DFL)
+def _view_array(ts):
+    views = [view(t) for t in ts]
+    arr = (C.POINTER(View) * len(views))(*[C.pointer(v) for v in views])
+    return arr, views
+
+
+class DetectLossState:
+    """Device buffers of one v8DetectionLoss evaluation (kept for the backward call)."""
+    __slots__ = ('feats', 'strides', 'gt', 'n_gt', 'out5', 'ws', 'ws_bytes', 'reg_max', 'nc', 'gains', 'fg', 'gt_idx', 'tscore')
+
+
+def detect_loss_fwd(feats, strides, reg_max, nc, gt, call_count, gains, want_assignment=False):
+    """feats: list of (B, 4R+nc, H, W) NHWC tensors; gt: (B, N, 5) fp32 cuda [cls, x1, y1, x2, y2] px.  Returns DetectLossState."""
+    lib = L.lib()
+    for f in feats:
+        _need_gpu(f)
+        if not is_nhwc(f):
+            raise RuntimeError('detect_loss: head maps must be channels_last (NHWC) tensors')
+    dev = feats[0].device
+    b = feats[0].shape[0]
+    a_total = sum(f.shape[2] * f.shape[3] for f in feats)
+    n_gt = int(gt.shape[1])
+    st = DetectLossState()
+    st.feats, st.reg_max, st.nc, st.gains, st.n_gt = feats, reg_max, nc, gains, n_gt
+    st.strides = torch.tensor([float(s) for s in strides], dtype=torch.float32)      # host array for the C call
+    st.gt = gt.contiguous().float()
+    st.out5 = torch.zeros(5, dtype=torch.float32, device=dev)
+    st.ws_bytes = lib.mgdt_detect_loss_workspace_bytes(b, a_total, n_gt)
+    st.ws = torch.empty(st.ws_bytes, dtype=torch.uint8, device=dev)
+    st.fg = torch.empty(b, a_total, dtype=torch.uint8, device=dev) if want_assignment else None
+    st.gt_idx = torch.empty(b, a_total, dtype=torch.int32, device=dev) if want_assignment else None
+    st.tscore = torch.empty(b, a_total, dtype=torch.float32, device=dev) if want_assignment else None
+    arr, keep = _view_array(feats)
+    sarr = (C.c_float * len(feats))(*st.strides.tolist())
+    _launch('detect_loss_fwd', 'mgdt_detect_loss_fwd', arr, sarr, len(feats), reg_max, nc, ptr(st.gt) if n_gt else None, n_gt, int(call_count),
+            float(gains[0]), float(gains[1]), float(gains[2]), ptr(st.out5), ptr(st.fg), ptr(st.gt_idx), ptr(st.tscore), ptr(st.ws), st.ws_bytes,
+            dtype_code(feats[0].dtype), stream())
+    return st
+
+
+def detect_loss_bwd(st, gscale=1.0):
+    """d(loss*B)/d feats for the state of a previous detect_loss_fwd; returns a list of NHWC grads."""
+    grads = [torch.empty_like(f) for f in st.feats]
+    arr, keep = _view_array(st.feats)
+    garr, gkeep = _view_array(grads)
+    sarr = (C.c_float * len(st.feats))(*st.strides.tolist())
+    _launch('detect_loss_bwd', 'mgdt_detect_loss_bwd', arr, garr, sarr, len(st.feats), st.reg_max, st.nc, ptr(st.gt) if st.n_gt else None, st.n_gt,
+            float(st.gains[0]), float(st.gains[1]), float(st.gains[2]), float(gscale), ptr(st.out5), ptr(st.ws), st.ws_bytes,
+            dtype_code(st.feats[0].dtype), stream())
+    return grads
