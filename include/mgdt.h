@@ -139,6 +139,26 @@ int mgdt_detect_loss_bwd(const mgdt_view* const* feats, const mgdt_view* const* 
                          int reg_max, int nc, const float* gt, int n_gt, float gain_box, float gain_cls, float gain_dfl,
                          float gscale, const float* out5, void* ws, size_t ws_bytes, int dtype, mgdt_stream s);
 
+/* ---- training side: BatchNorm2d (batch statistics) + activation, its backward, conv dgrad / wgrad, adjoints ----------------
+ * Conv.forward in training mode (nn/modules/conv.py:36-38: act(bn(conv(x))) with nn.BatchNorm2d eps 1e-3 / momentum 0.03,
+ * yolo/utils/torch_utils.py:254-256) and what torch.autograd derives from it in trainer.py:343 (`scaler.scale(loss).backward()`).
+ * ws: mgdt_reduce_workspace_bytes(c) / mgdt_conv_wgrad_workspace_bytes(cin, cout, k) bytes; all reductions have a fixed order.  */
+size_t mgdt_reduce_workspace_bytes(int c);
+int mgdt_bn_stats_fwd(const mgdt_view* y, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                      float* running_var, void* ws, int dtype, mgdt_stream s);
+int mgdt_bn_act_fwd(const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                    const mgdt_view* r1, const mgdt_view* r2, const mgdt_view* z, int dtype, mgdt_stream s);
+int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int act, float* dgamma, float* dbeta, const mgdt_view* dy, void* ws, int dtype, mgdt_stream s);
+int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, int stride, const mgdt_view* dx, int accumulate, int dtype,
+                    mgdt_stream s);
+size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k);
+int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
+                    int accumulate, void* ws, int dtype, mgdt_stream s);
+int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, mgdt_stream s);
+int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, mgdt_stream s);
+int mgdt_nearest_bwd(const mgdt_view* gy, const mgdt_view* gx, int dtype, mgdt_stream s);
+
 #ifdef __cplusplus
 }
 #endif

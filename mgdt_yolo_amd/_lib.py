@@ -46,6 +46,16 @@ PROTOTYPES = {
     'mgdt_detect_loss_workspace_bytes': (_sz, [_i, _i, _i]),
     'mgdt_detect_loss_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     'mgdt_detect_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
+    'mgdt_reduce_workspace_bytes': (_sz, [_i]),
+    'mgdt_bn_stats_fwd': (_i, [VP, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mgdt_bn_act_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _i, VP, VP, VP, _i, _vp]),
+    'mgdt_bn_act_bwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _vp, _vp, VP, _vp, _i, _vp]),
+    'mgdt_conv_dgrad': (_i, [VP, _vp, _i, _i, VP, _i, _i, _vp]),
+    'mgdt_conv_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
+    'mgdt_conv_wgrad': (_i, [VP, VP, VP, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'mgdt_add_fwd': (_i, [VP, VP, VP, _i, _vp]),
+    'mgdt_maxpool5_bwd': (_i, [VP, VP, _vp, _i, _vp]),
+    'mgdt_nearest_bwd': (_i, [VP, VP, _i, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

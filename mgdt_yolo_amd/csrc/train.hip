@@ -1,0 +1,487 @@
+// Training-side kernels of the detection path: BatchNorm2d in training mode (batch statistics, running-stat update,
+// fused activation and residual adds), its backward, convolution dgrad / wgrad / bias-grad, and the adjoints of the pooling /
+// resampling ops.  First-cut versions: correct, deterministic (fixed-order reductions, no float atomics except max-pool
+// routing), channel-vectorised; the MFMA treatment the forward convolution got is the next step for dgrad(stride 2) / wgrad.
+// Reference semantics: nn.BatchNorm2d(eps 1e-3, momentum 0.03) as set by initialize_weights (yolo/utils/torch_utils.py:254-256):
+// normalise with the biased batch variance, update running_var with the unbiased one.
+#include "common.h"
+
+#define RED_SPLITS 32
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+  switch (act) {
+    case MGDT_ACT_SILU: return u / (1.f + expf(-u));
+    case MGDT_ACT_RELU: return fmaxf(u, 0.f);
+    case MGDT_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+    default: return u;
+  }
+}
+__device__ __forceinline__ float act_grad(float u, int act) {
+  switch (act) {
+    case MGDT_ACT_SILU: { float s = 1.f / (1.f + expf(-u)); return s * (1.f + u * (1.f - s)); }
+    case MGDT_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case MGDT_ACT_GELU: return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+    default: return 1.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ per-channel reductions
+// partial[split][c][2] (double) = sum over the split's pixels of (f0, f1); pixel ranges are fixed -> deterministic.
+template <typename T, typename F>
+__device__ __forceinline__ void channel_reduce(const mgdt_view v, double* partial, F f) {
+  // grid: (cdiv(C,64), RED_SPLITS); block 256 = 64 channels x 4 pixel lanes
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6, split = blockIdx.y;
+  const long npix = (long)v.n * v.h * v.w;
+  const long p0 = split * npix / RED_SPLITS, p1 = (split + 1) * npix / RED_SPLITS;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < v.c) {
+    const long HW = (long)v.h * v.w;
+    for (long p = p0 + pl; p < p1; p += 4) {
+      long n = p / HW, rem = p - n * HW;
+      long yy = rem / v.w, xx = rem - yy * v.w;
+      float a0, a1;
+      f(n * v.sn + yy * v.sh + xx * v.sw + c, n, yy, xx, c, a0, a1);
+      s0 += a0;
+      s1 += a1;
+    }
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < v.c) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < 4; ++k) { t0 += red[0][k * 64 + threadIdx.x]; t1 += red[1][k * 64 + threadIdx.x]; }
+    partial[((long)split * v.c + c) * 2] = t0;
+    partial[((long)split * v.c + c) * 2 + 1] = t1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const mgdt_view y, double* partial) {
+  const T* p = (const T*)y.p;
+  channel_reduce<T>(y, partial, [&](long off, long, long, long, int, float& a0, float& a1) { float v = (float)p[off]; a0 = v; a1 = v * v; });
+}
+
+__global__ void bn_stats_final_kernel(const double* partial, int C, double count, float eps, float momentum, float* mean, float* rstd,
+                                      float* running_mean, float* running_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < RED_SPLITS; ++k) { s += partial[((long)k * C + c) * 2]; ss += partial[((long)k * C + c) * 2 + 1]; }
+  double m = s / count, var = ss / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+extern "C" size_t mgdt_reduce_workspace_bytes(int c) { return (size_t)RED_SPLITS * c * 2 * sizeof(double); }
+
+extern "C" int mgdt_bn_stats_fwd(const mgdt_view* y, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, void* ws, int dtype, mgdt_stream s) {
+  if (!view_ok(y) || !mean || !rstd || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_stats: null/empty argument");
+  if (y->sc != 1) MGDT_FAIL(MGDT_BAD_SHAPE, "bn_stats: NHWC view required");
+  dim3 grid(cdiv(y->c, 64), RED_SPLITS);
+  MGDT_DISPATCH_DTYPE(dtype, (bn_stats_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*y, (double*)ws)));
+  bn_stats_final_kernel<<<cdiv(y->c, 256), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
+                                                                     running_mean, running_var);
+  MGDT_CHECK_LAUNCH("bn_stats_fwd");
+  return MGDT_OK;
+}
+
+// z = act(gamma * (y - mean) * rstd + beta) [+ r1] [+ r2]   (gamma/beta/mean/rstd may be NULL -> plain act(y + bias?))
+template <typename T>
+__global__ void bn_act_fwd_kernel(const mgdt_view y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                  const mgdt_view r1, const mgdt_view r2, const mgdt_view z) {
+  long total = (long)y.n * y.h * y.w * y.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % y.c);
+    long t = i / y.c;
+    int w = (int)(t % y.w);
+    t /= y.w;
+    int h = (int)(t % y.h);
+    long n = t / y.h;
+    float v = (float)((const T*)y.p)[n * y.sn + h * y.sh + w * y.sw + c];
+    float u = mean ? gamma[c] * ((v - mean[c]) * rstd[c]) + beta[c] : v + (beta ? beta[c] : 0.f);
+    float o = act_fwd(u, act);
+    if (r1.p) o += (float)((const T*)r1.p)[n * r1.sn + h * r1.sh + w * r1.sw + c];
+    if (r2.p) o += (float)((const T*)r2.p)[n * r2.sn + h * r2.sh + w * r2.sw + c];
+    ((T*)z.p)[n * z.sn + h * z.sh + w * z.sw + c] = (T)o;
+  }
+}
+
+static mgdt_view null_view() { mgdt_view v; memset(&v, 0, sizeof(v)); return v; }
+static inline int ew_grid(long total) { return (int)std::min<long>((total + 255) / 256, 16384); }
+
+extern "C" int mgdt_bn_act_fwd(const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                               const mgdt_view* r1, const mgdt_view* r2, const mgdt_view* z, int dtype, mgdt_stream s) {
+  if (!view_ok(y) || !view_ok(z)) MGDT_FAIL(MGDT_BAD_ARG, "bn_act: null/empty view");
+  if (y->sc != 1 || z->sc != 1 || y->n != z->n || y->h != z->h || y->w != z->w || y->c != z->c) MGDT_FAIL(MGDT_BAD_SHAPE, "bn_act: matching NHWC views required");
+  if ((mean != nullptr) != (rstd != nullptr) || (mean && (!gamma || !beta))) MGDT_FAIL(MGDT_BAD_ARG, "bn_act: mean/rstd/gamma/beta must come together");
+  long total = (long)y->n * y->h * y->w * y->c;
+  mgdt_view a = (r1 && r1->p) ? *r1 : null_view(), b = (r2 && r2->p) ? *r2 : null_view();
+  MGDT_DISPATCH_DTYPE(dtype, (bn_act_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*y, mean, rstd, gamma, beta, act, a, b, *z)));
+  MGDT_CHECK_LAUNCH("bn_act_fwd");
+  return MGDT_OK;
+}
+
+// backward of z = act(u), u = gamma*xhat + beta, xhat = (y-mean)*rstd:
+//   g = gz * act'(u); dbeta = sum g; dgamma = sum g*xhat; dy = gamma*rstd*(g - dbeta/m - xhat*dgamma/m)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const mgdt_view gz, const mgdt_view y, const float* mean, const float* rstd,
+                                                             const float* gamma, const float* beta, int act, double* partial) {
+  const T* gp = (const T*)gz.p;
+  const T* yp = (const T*)y.p;
+  channel_reduce<T>(gz, partial, [&](long off, long n, long yy, long xx, int c, float& a0, float& a1) {
+    float v = (float)yp[n * y.sn + yy * y.sh + xx * y.sw + c];
+    float xh = mean ? (v - mean[c]) * rstd[c] : v;
+    float u = mean ? gamma[c] * xh + beta[c] : v + (beta ? beta[c] : 0.f);
+    float g = (float)gp[off] * act_grad(u, act);
+    a0 = g;
+    a1 = g * xh;
+  });
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const mgdt_view gz, const mgdt_view y, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, int act, const double* partial, double count, float* dgamma, float* dbeta,
+                                    const mgdt_view dy) {
+  long total = (long)y.n * y.h * y.w * y.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % y.c);
+    long t = i / y.c;
+    int w = (int)(t % y.w);
+    t /= y.w;
+    int h = (int)(t % y.h);
+    long n = t / y.h;
+    double sg = 0.0, sgx = 0.0;
+    for (int k = 0; k < RED_SPLITS; ++k) { sg += partial[((long)k * y.c + c) * 2]; sgx += partial[((long)k * y.c + c) * 2 + 1]; }
+    if (n == 0 && h == 0 && w == 0) {
+      if (dbeta) dbeta[c] = (float)sg;
+      if (dgamma) dgamma[c] = (float)sgx;
+    }
+    float v = (float)((const T*)y.p)[n * y.sn + h * y.sh + w * y.sw + c];
+    float gzv = (float)((const T*)gz.p)[n * gz.sn + h * gz.sh + w * gz.sw + c];
+    float o;
+    if (mean) {
+      float xh = (v - mean[c]) * rstd[c];
+      float g = gzv * act_grad(gamma[c] * xh + beta[c], act);
+      o = gamma[c] * rstd[c] * (g - (float)(sg / count) - xh * (float)(sgx / count));
+    } else {
+      o = gzv * act_grad(v + (beta ? beta[c] : 0.f), act);
+    }
+    ((T*)dy.p)[n * dy.sn + h * dy.sh + w * dy.sw + c] = (T)o;
+  }
+}
+
+extern "C" int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int act, float* dgamma, float* dbeta, const mgdt_view* dy, void* ws, int dtype,
+                               mgdt_stream s) {
+  if (!view_ok(gz) || !view_ok(y) || !view_ok(dy) || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_act_bwd: null/empty argument");
+  if (gz->sc != 1 || y->sc != 1 || dy->sc != 1 || gz->c != y->c || dy->c != y->c || gz->n != y->n || gz->h != y->h || gz->w != y->w)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "bn_act_bwd: matching NHWC views required");
+  dim3 grid(cdiv(y->c, 64), RED_SPLITS);
+  long total = (long)y->n * y->h * y->w * y->c;
+  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (double*)ws)));
+  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (const double*)ws,
+                                                                                               (double)y->n * y->h * y->w, dgamma, dbeta, *dy)));
+  MGDT_CHECK_LAUNCH("bn_act_bwd");
+  return MGDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conv dgrad (direct, any stride)
+// dx[n,iy,ix,ci] (+)= sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * w[co][ci][ky][kx]   (only where divisible by s)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(const mgdt_view dy, const float* __restrict__ w, int KS, int stride, int Cin_tot,
+                                                         const mgdt_view dx, int accumulate) {
+  // thread = (input pixel, 4 input channels)
+  const int Q = dx.c / 4;
+  long total = (long)dx.n * dx.h * dx.w * Q;
+  const int pad = KS / 2, Cout = dy.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int q = (int)(i % Q);
+    long t = i / Q;
+    int ix = (int)(t % dx.w);
+    t /= dx.w;
+    int iy = (int)(t % dx.h);
+    long n = t / dx.h;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < KS; ++ky) {
+      int ty = iy + pad - ky;
+      if (ty < 0 || ty % stride) continue;
+      int oy = ty / stride;
+      if (oy >= dy.h) continue;
+      for (int kx = 0; kx < KS; ++kx) {
+        int tx = ix + pad - kx;
+        if (tx < 0 || tx % stride) continue;
+        int ox = tx / stride;
+        if (ox >= dy.w) continue;
+        const T* gp = (const T*)dy.p + n * dy.sn + oy * dy.sh + ox * dy.sw;
+        for (int co = 0; co < Cout; ++co) {
+          float g = (float)gp[co];
+          const float* wp = w + (((long)co * Cin_tot + q * 4) * KS + ky) * KS + kx;
+          const long cs = (long)KS * KS;
+          acc[0] = fmaf(g, wp[0], acc[0]);
+          acc[1] = fmaf(g, wp[cs], acc[1]);
+          acc[2] = fmaf(g, wp[2 * cs], acc[2]);
+          acc[3] = fmaf(g, wp[3 * cs], acc[3]);
+        }
+      }
+    }
+    T* op = (T*)dx.p + n * dx.sn + iy * dx.sh + ix * dx.sw + q * 4;
+    if (accumulate) acc += load4<T>(op);
+    store4<T>(op, acc);
+  }
+}
+
+extern "C" int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, int stride, const mgdt_view* dx, int accumulate, int dtype,
+                               mgdt_stream s) {
+  if (!view_ok(dy) || !view_ok(dx) || !w_oihw) MGDT_FAIL(MGDT_BAD_ARG, "conv_dgrad: null/empty argument");
+  if (dy->sc != 1 || dx->sc != 1 || dx->c % 4 || dx->sw % 4 || dx->sh % 4 || dx->sn % 4 || dy->n != dx->n) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_dgrad: NHWC views, cin%%4==0");
+  const int pad = k / 2;
+  if ((dx->h + 2 * pad - k) / stride + 1 != dy->h || (dx->w + 2 * pad - k) / stride + 1 != dy->w) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_dgrad: dy/dx geometry mismatch");
+  long total = (long)dx->n * dx->h * dx->w * (dx->c / 4);
+  MGDT_DISPATCH_DTYPE(dtype, (conv_dgrad_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*dy, w_oihw, k, stride, dx->c, *dx, accumulate)));
+  MGDT_CHECK_LAUNCH("conv_dgrad");
+  return MGDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conv wgrad (+ bias grad)
+// dw[co][ci][ky][kx] = sum_{n,oy,ox} dy[n,oy,ox,co] * (x [+ x2])[n, oy*s-pad+ky, ox*s-pad+kx, ci]
+// block = one tap x 16 couts x 16 cins x one pixel split; 256 threads = 16 (co quad, ci quad) pairs x 16 pixel lanes.
+#define WG_SPLITS 16
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view x, const mgdt_view x2, const mgdt_view dy, int KS, int stride,
+                                                                 float* __restrict__ partial) {
+  const int tap = blockIdx.z % (KS * KS), split = blockIdx.z / (KS * KS);
+  const int ky = tap / KS, kx = tap % KS, pad = KS / 2;
+  const int co0 = blockIdx.x * 16, ci0 = blockIdx.y * 16;
+  const int pair = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int coq = co0 + (pair >> 2) * 4, ciq = ci0 + (pair & 3) * 4;
+  const long M = (long)dy.n * dy.h * dy.w, HW = (long)dy.h * dy.w;
+  const long p0 = split * M / WG_SPLITS, p1 = (split + 1) * M / WG_SPLITS;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  const bool live = coq < dy.c && ciq < x.c;
+  if (live) {
+    for (long p = p0 + pl; p < p1; p += 16) {
+      long n = p / HW, rem = p - n * HW;
+      int oy = (int)(rem / dy.w), ox = (int)(rem - (long)oy * dy.w);
+      int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if ((unsigned)iy >= (unsigned)x.h || (unsigned)ix >= (unsigned)x.w) continue;
+      f32x4 g = load4<T>((const T*)dy.p + n * dy.sn + oy * dy.sh + ox * dy.sw + coq);
+      f32x4 v = load4<T>((const T*)x.p + n * x.sn + iy * x.sh + ix * x.sw + ciq);
+      if (x2.p) v += load4<T>((const T*)x2.p + n * x2.sn + iy * x2.sh + ix * x2.sw + ciq);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(g[a], v[b], acc[a][b]);
+    }
+  }
+  __shared__ float red[16][16][17];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) red[pl][pair][a * 4 + b] = acc[a][b];
+  __syncthreads();
+  // thread t sums element (pair = t / 16, e = t % 16) over the 16 pixel lanes
+  {
+    int pr = threadIdx.x >> 4, e = threadIdx.x & 15;
+    float sum = 0.f;
+    for (int k = 0; k < 16; ++k) sum += red[k][pr][e];
+    int co = co0 + (pr >> 2) * 4 + (e >> 2), ci = ci0 + (pr & 3) * 4 + (e & 3);
+    if (co < dy.c && ci < x.c) partial[(((long)split * dy.c + co) * x.c + ci) * KS * KS + tap] = sum;
+  }
+}
+
+__global__ void wgrad_final_kernel(const float* partial, long n, float* dw, int accumulate) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < WG_SPLITS; ++k) s += partial[(long)k * n + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const mgdt_view dy, double* partial) {
+  const T* p = (const T*)dy.p;
+  channel_reduce<T>(dy, partial, [&](long off, long, long, long, int, float& a0, float& a1) { a0 = (float)p[off]; a1 = 0.f; });
+}
+__global__ void bias_grad_final_kernel(const double* partial, int C, float* db, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < RED_SPLITS; ++k) s += partial[((long)k * C + c) * 2];
+  db[c] = accumulate ? db[c] + (float)s : (float)s;
+}
+
+// generic-stride variant (the 3-channel stem reads the NCHW image): one block per weight element, fixed-order tree reduction
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const mgdt_view x, const mgdt_view dy, int KS, int stride, float* __restrict__ dw,
+                                                                 int accumulate) {
+  const int e = blockIdx.x;                       // ((co * Cin + ci) * KS + ky) * KS + kx
+  const int kx = e % KS, ky = (e / KS) % KS, ci = (e / (KS * KS)) % x.c, co = e / (KS * KS * x.c);
+  const int pad = KS / 2;
+  const long M = (long)dy.n * dy.h * dy.w, HW = (long)dy.h * dy.w;
+  double acc = 0.0;
+  for (long p = threadIdx.x; p < M; p += 256) {
+    long n = p / HW, rem = p - n * HW;
+    int oy = (int)(rem / dy.w), ox = (int)(rem - (long)oy * dy.w);
+    int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    if ((unsigned)iy >= (unsigned)x.h || (unsigned)ix >= (unsigned)x.w) continue;
+    acc += (double)((float)((const T*)dy.p)[n * dy.sn + oy * dy.sh + ox * dy.sw + co * dy.sc] *
+                    (float)((const TX*)x.p)[n * x.sn + iy * x.sh + ix * x.sw + ci * x.sc]);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dw[e] = accumulate ? dw[e] + (float)red[0] : (float)red[0];
+}
+
+extern "C" size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k) {
+  return std::max((size_t)WG_SPLITS * cin * cout * k * k * sizeof(float), mgdt_reduce_workspace_bytes(cout));
+}
+
+extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
+                               int accumulate, void* ws, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(dy) || !dw_oihw || !ws) MGDT_FAIL(MGDT_BAD_ARG, "conv_wgrad: null/empty argument");
+  hipStream_t st = (hipStream_t)s;
+  if (dy->sc != 1 || x->n != dy->n) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: dy must be an NHWC view with the batch of x");
+  if (x->sc != 1 || x->c % 4 || dy->c % 4) {   // generic path: fp32 input of any layout (the image), no fused x2
+    if (x2 && x2->p) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: x2 needs the NHWC path");
+    int nel = dy->c * x->c * k * k;
+    if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
+    else conv_wgrad_generic_kernel<float, bf16><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
+    if (dbias) {
+      dim3 g2(cdiv(dy->c, 64), RED_SPLITS);
+      MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
+      bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
+    }
+    MGDT_CHECK_LAUNCH("conv_wgrad(generic)");
+    return MGDT_OK;
+  }
+  mgdt_view b = (x2 && x2->p) ? *x2 : null_view();
+  dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * WG_SPLITS);
+  MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws)));
+  long n = (long)dy->c * x->c * k * k;
+  wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate);
+  if (dbias) {
+    dim3 g2(cdiv(dy->c, 64), RED_SPLITS);
+    MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
+    bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
+  }
+  MGDT_CHECK_LAUNCH("conv_wgrad");
+  return MGDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise add / adjoints
+template <typename T>
+__global__ void add_kernel(const mgdt_view a, const mgdt_view b, const mgdt_view o) {
+  long total = (long)o.n * o.h * o.w * o.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % o.c);
+    long t = i / o.c;
+    int w = (int)(t % o.w);
+    t /= o.w;
+    int h = (int)(t % o.h);
+    long n = t / o.h;
+    float v = (float)((const T*)a.p)[n * a.sn + h * a.sh + w * a.sw + c * a.sc] + (float)((const T*)b.p)[n * b.sn + h * b.sh + w * b.sw + c * b.sc];
+    ((T*)o.p)[n * o.sn + h * o.sh + w * o.sw + c * o.sc] = (T)v;
+  }
+}
+
+extern "C" int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, mgdt_stream s) {
+  if (!view_ok(a) || !view_ok(b) || !view_ok(o)) MGDT_FAIL(MGDT_BAD_ARG, "add: null/empty view");
+  if (a->n != o->n || a->h != o->h || a->w != o->w || a->c != o->c || b->n != o->n || b->h != o->h || b->w != o->w || b->c != o->c)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "add: shape mismatch");
+  long total = (long)o->n * o->h * o->w * o->c;
+  MGDT_DISPATCH_DTYPE(dtype, (add_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*a, *b, *o)));
+  MGDT_CHECK_LAUNCH("add_fwd");
+  return MGDT_OK;
+}
+
+// MaxPool2d(5,1,2) backward: gx[argmax window(o)] += gy[o]; argmax = first maximum in (ky, kx) scan order (ATen semantics).
+template <typename T>
+__global__ void maxpool5_bwd_kernel(const mgdt_view x, const mgdt_view gy, float* gx_f32) {
+  long total = (long)x.n * x.h * x.w * x.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % x.c);
+    long t = i / x.c;
+    int w = (int)(t % x.w);
+    t /= x.w;
+    int h = (int)(t % x.h);
+    long n = t / x.h;
+    float best = -INFINITY;
+    int by = h, bx = w;
+    for (int dy = -2; dy <= 2; ++dy) {
+      int yy = h + dy;
+      if ((unsigned)yy >= (unsigned)x.h) continue;
+      for (int dx = -2; dx <= 2; ++dx) {
+        int xx = w + dx;
+        if ((unsigned)xx >= (unsigned)x.w) continue;
+        float v = (float)((const T*)x.p)[n * x.sn + yy * x.sh + xx * x.sw + c];
+        if (v > best || isnan(v)) { best = v; by = yy; bx = xx; }
+      }
+    }
+    float g = (float)((const T*)gy.p)[n * gy.sn + h * gy.sh + w * gy.sw + c];
+    atomicAdd(gx_f32 + ((n * x.h + by) * x.w + bx) * x.c + c, g);
+  }
+}
+
+// gx_f32: dense fp32 [n][h][w][c] accumulator, zeroed by the caller (hipMemsetAsync) - the P5 map is tiny.
+extern "C" int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(gy) || !gx_f32) MGDT_FAIL(MGDT_BAD_ARG, "maxpool5_bwd: null/empty argument");
+  if (x->sc != 1 || gy->sc != 1 || x->n != gy->n || x->h != gy->h || x->w != gy->w || x->c != gy->c) MGDT_FAIL(MGDT_BAD_SHAPE, "maxpool5_bwd: matching NHWC views");
+  long total = (long)x->n * x->h * x->w * x->c;
+  MGDT_DISPATCH_DTYPE(dtype, (maxpool5_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*x, *gy, gx_f32)));
+  MGDT_CHECK_LAUNCH("maxpool5_bwd");
+  return MGDT_OK;
+}
+
+// nearest x(scale) up-sampling adjoint: gx[iy,ix] = sum of the gy pixels that read it
+template <typename T>
+__global__ void nearest_bwd_kernel(const mgdt_view gy, const mgdt_view gx) {
+  long total = (long)gx.n * gx.h * gx.w * gx.c;
+  const float sy = (float)gx.h / (float)gy.h, sx = (float)gx.w / (float)gy.w;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % gx.c);
+    long t = i / gx.c;
+    int w = (int)(t % gx.w);
+    t /= gx.w;
+    int h = (int)(t % gx.h);
+    long n = t / gx.h;
+    // candidate outputs: a small bracket around [h/scale, (h+1)/scale), each verified with the forward's index rule
+    const int oy_lo = max(0, (int)floorf((float)h / sy) - 1), oy_hi = min(gy.h - 1, (int)ceilf((float)(h + 1) / sy) + 1);
+    const int ox_lo = max(0, (int)floorf((float)w / sx) - 1), ox_hi = min(gy.w - 1, (int)ceilf((float)(w + 1) / sx) + 1);
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (min((int)floorf((float)oy * sy), gx.h - 1) != h) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (min((int)floorf((float)ox * sx), gx.w - 1) != w) continue;
+        acc += (float)((const T*)gy.p)[n * gy.sn + oy * gy.sh + ox * gy.sw + c];
+      }
+    }
+    ((T*)gx.p)[n * gx.sn + h * gx.sh + w * gx.sw + c] = (T)acc;
+  }
+}
+
+extern "C" int mgdt_nearest_bwd(const mgdt_view* gy, const mgdt_view* gx, int dtype, mgdt_stream s) {
+  if (!view_ok(gy) || !view_ok(gx)) MGDT_FAIL(MGDT_BAD_ARG, "nearest_bwd: null/empty view");
+  if (gy->sc != 1 || gx->sc != 1 || gy->n != gx->n || gy->c != gx->c) MGDT_FAIL(MGDT_BAD_SHAPE, "nearest_bwd: NHWC views, same n/c");
+  long total = (long)gx->n * gx->h * gx->w * gx->c;
+  MGDT_DISPATCH_DTYPE(dtype, (nearest_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gy, *gx)));
+  MGDT_CHECK_LAUNCH("nearest_bwd");
+  return MGDT_OK;
+}

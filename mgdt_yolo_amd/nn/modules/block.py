@@ -41,8 +41,16 @@ class Bottleneck(HipModule):
 
     def run(self, x, out=None, x2=None):
         """y = [x (+x2)] + cv2(cv1(x (+x2))); `x2` is MSPA's pending `sp + spx[i]` add."""
+        if self.training and hasattr(self.cv1, 'bn'):
+            t = self.cv1.train_fwd(x, x2=x2)
+            return self.cv2.train_fwd(t, out=out, r1=x if self.add else None, r2=x2 if self.add else None)
         t = self.cv1.run(x, x2=x2)
         return self.cv2.run(t, out=out, r1=x if self.add else None, r2=x2 if self.add else None)
+
+    def backward(self, gz):
+        """Returns d/d(x [+ x2]) (the same tensor is the gradient of both addends)."""
+        gx = self.cv1.backward(self.cv2.backward(gz))
+        return ops.add(gx, gz, out=gx) if self.add else gx
 
     def forward(self, x):
         return self.run(x)
@@ -61,13 +69,23 @@ class C2f(HipModule):
     def forward(self, x):
         b, _, h, w = x.shape
         c, n = self.c, len(self.m)
+        train = self.training and hasattr(self.cv1, 'bn')
         cat = ops.new_act(b, (2 + n) * c, h, w, self.cv1.out_dtype(x), x.device)
-        self.cv1.run(x, out=cat[:, :2 * c])
+        (self.cv1.train_fwd if train else self.cv1.run)(x, out=cat[:, :2 * c])
         for j, m in enumerate(self.m):
             m.run(cat[:, (1 + j) * c:(2 + j) * c], out=cat[:, (2 + j) * c:(3 + j) * c])
-        return self.cv2.run(cat)
+        return (self.cv2.train_fwd if train else self.cv2.run)(cat)
 
     forward_split = forward
+
+    def backward(self, g):
+        c, n = self.c, len(self.m)
+        gcat = self.cv2.backward(g)                                   # grad of the concat buffer
+        for j in reversed(range(n)):                                  # bottleneck j: slot 1+j -> slot 2+j
+            gin = self.m[j].backward(gcat[:, (2 + j) * c:(3 + j) * c])
+            dst = gcat[:, (1 + j) * c:(2 + j) * c]
+            ops.add(dst, gin, out=dst)
+        return self.cv1.backward(gcat[:, :2 * c])
 
 
 class MSPA_C2f(HipModule):
@@ -128,10 +146,24 @@ class SPPF(HipModule):
     def forward(self, x):
         b, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
+        train = self.training and hasattr(self.cv1, 'bn')
         cat = ops.new_act(b, 4 * c_, h, w, self.cv1.out_dtype(x), x.device)
-        self.cv1.run(x, out=cat[:, :c_])
+        (self.cv1.train_fwd if train else self.cv1.run)(x, out=cat[:, :c_])
         ops.sppf_pools(cat[:, :c_], cat[:, c_:2 * c_], cat[:, 2 * c_:3 * c_], cat[:, 3 * c_:])
-        return self.cv2.run(cat)
+        if train:
+            self._cat = cat
+        return (self.cv2.train_fwd if train else self.cv2.run)(cat)
+
+    def backward(self, g):
+        c_ = self.cv1.conv.out_channels
+        cat, self._cat = self._cat, None
+        gcat = self.cv2.backward(g)
+        sl = lambda t, i: t[:, i * c_:(i + 1) * c_]
+        # y3 = mp(y2), y2 = mp(y1), y1 = mp(x0): route the gradients back through the three max-pools
+        g2 = ops.add(sl(gcat, 2), ops.maxpool5_bwd(sl(cat, 2), sl(gcat, 3)))
+        g1 = ops.add(sl(gcat, 1), ops.maxpool5_bwd(sl(cat, 1), g2))
+        g0 = ops.add(sl(gcat, 0), ops.maxpool5_bwd(sl(cat, 0), g1))
+        return self.cv1.backward(g0)
 
 
 class Upsample(nn.Module):
@@ -147,6 +179,10 @@ class Upsample(nn.Module):
         b, c, h, w = x.shape
         out = ops.new_act(b, c, int(h * self.scale_factor), int(w * self.scale_factor), x.dtype, x.device)
         return ops.nearest(x, out)
+
+    def backward(self, g):
+        b, c, h, w = g.shape
+        return ops.nearest_bwd(g, ops.new_act(b, c, int(h / self.scale_factor), int(w / self.scale_factor), g.dtype, g.device))
 
 
 class SimFusion_4in(nn.Module):

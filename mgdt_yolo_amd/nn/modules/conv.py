@@ -97,7 +97,40 @@ class Conv(HipModule):
         return ops.conv2d(x, pk, s, act_code(self.act), out=out, x2=x2, r1=r1, r2=r2, in_scale=in_scale, in_shift=in_shift)
 
     def forward(self, x):
+        if self.training and hasattr(self, 'bn'):
+            return self.train_fwd(x)
         return self.run(x)
+
+    # -- training mode: batch-statistics BN, context for backward ---------------------------------------------
+    def train_fwd(self, x, out=None, x2=None, r1=None, r2=None):
+        """act(bn_batchstats(conv(x [+ x2]))) [+ r1] [+ r2]; keeps (x, x2, raw conv output, mean, rstd) for backward()."""
+        k, s = self._geometry()
+        dt = self.out_dtype(x) if out is None else out.dtype
+        if dt != torch.float32:
+            raise NotImplementedError('training runs in float32 in this round (bf16 training kernels: next)')
+        mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
+        pk = self._cached(('raw', dt, not mfma), [self.conv.weight],
+                          lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma, groups=self.conv.groups))
+        y = ops.conv2d(x, pk, s, ops.ACT_NONE, x2=x2 if mfma else None)
+        bn = self.bn
+        mean, rstd = ops.bn_stats(y, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        z = ops.bn_act(y, mean, rstd, bn.weight, bn.bias, act_code(self.act), out=out, r1=r1, r2=r2)
+        self.__dict__.setdefault('_ctx', []).append((x, x2, y, mean, rstd, k, s))
+        return z
+
+    def backward(self, gz, need_dx=True):
+        """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx."""
+        x, x2, y, mean, rstd, k, s = self._ctx.pop()
+        bn = self.bn
+        bn.weight.grad = torch.empty_like(bn.weight)
+        bn.bias.grad = torch.empty_like(bn.bias)
+        dy = ops.bn_act_bwd(gz, y, mean, rstd, bn.weight, bn.bias, act_code(self.act), bn.weight.grad, bn.bias.grad)
+        self.conv.weight.grad = torch.empty_like(self.conv.weight)
+        ops.conv_wgrad(x, dy, k, s, self.conv.weight.grad, x2=x2)
+        if not need_dx:
+            return None
+        dx = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
+        return ops.conv_dgrad(dy, self.conv.weight, k, s, dx)
 
     def forward_fuse(self, x):
         """After BaseModel.fuse(): `bn` is gone and `conv` carries the folded weight + bias (conv.py:40-42)."""
@@ -118,9 +151,18 @@ class Concat(nn.Module):
         super().__init__()
         self.d = dimension
 
+    def backward(self, g):
+        """Adjoint of the channel concat: channel-slice views of g (no copies)."""
+        out, c0 = [], 0
+        for c in self._split:
+            out.append(g[:, c0:c0 + c])
+            c0 += c
+        return out
+
     def forward(self, x):
         if self.d != 1:
             raise RuntimeError('Concat: only channel concatenation (dimension=1) is on the detection path')
+        self._split = [t.shape[1] for t in x]
         b, _, h, w = x[0].shape
         out = ops.new_act(b, sum(t.shape[1] for t in x), h, w, x[0].dtype, x[0].device)
         c0 = 0

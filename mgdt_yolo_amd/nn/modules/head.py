@@ -26,6 +26,15 @@ class _HeadConv(HipModule):
                            lambda: ops.PackedConv(conv.weight, conv.bias, None, 1, out.dtype))
         return ops.conv2d(x, pk, 1, ops.ACT_NONE, out=out)
 
+    @staticmethod
+    def backward(conv, x, g):
+        """Plain conv + bias: fills conv.weight.grad / conv.bias.grad, returns dx."""
+        conv.weight.grad = torch.empty_like(conv.weight)
+        conv.bias.grad = torch.empty_like(conv.bias)
+        ops.conv_wgrad(x, g, 1, 1, conv.weight.grad, dbias=conv.bias.grad)
+        dx = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.dtype, x.device)
+        return ops.conv_dgrad(g, conv.weight, 1, 1, dx)
+
 
 class Detect(HipModule):
     """YOLOv8 Detect head for detection models (this fork: reg_max = 4, head.py:145)."""
@@ -56,10 +65,12 @@ class Detect(HipModule):
             xi = x[i]
             b, _, h, w = xi.shape
             feat = ops.new_act(b, self.no, h, w, self.cv2[i][0].out_dtype(xi), xi.device)
-            t = self.cv2[i][1].run(self.cv2[i][0].run(xi))
-            _HeadConv.run(self, self.cv2[i][2], t, feat[:, :r4])
-            t = self.cv3[i][1].run(self.cv3[i][0].run(xi))
-            _HeadConv.run(self, self.cv3[i][2], t, feat[:, r4:])
+            tb = self.cv2[i][1](self.cv2[i][0](xi))          # Conv.forward: eval -> fused run, train -> batch-stat BN + ctx
+            _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
+            tc = self.cv3[i][1](self.cv3[i][0](xi))
+            _HeadConv.run(self, self.cv3[i][2], tc, feat[:, r4:])
+            if self.training:
+                self.__dict__.setdefault('_ctx', []).append((tb, tc))
             x[i] = feat
         if self.training:
             return x
@@ -75,6 +86,18 @@ class Detect(HipModule):
             ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
+
+    def backward(self, grads):
+        """grads: list of d loss / d raw head maps (one per level, NHWC).  Returns the list of input gradients."""
+        r4 = 4 * self.reg_max
+        ctx = [self._ctx.pop() for _ in range(self.nl)][::-1]
+        out = []
+        for i, g in enumerate(grads):
+            tb, tc = ctx[i]
+            gb = self.cv2[i][0].backward(self.cv2[i][1].backward(_HeadConv.backward(self.cv2[i][2], tb, g[:, :r4])))
+            gc = self.cv3[i][0].backward(self.cv3[i][1].backward(_HeadConv.backward(self.cv3[i][2], tc, g[:, r4:])))
+            out.append(ops.add(gb, gc, out=gb))
+        return out
 
     def bias_init(self):
         """Initialize Detect() biases (reference head.py:179-186); requires stride availability."""

@@ -51,6 +51,35 @@ class BaseModel(nn.Module):
             y.append(x if m.i in self.save else None)
         return x
 
+    def backward(self, head_grads):
+        """Explicit reverse pass over the layer list (the counterpart of `_predict_once`; replaces torch.autograd on the
+        hot path): `head_grads` = d loss / d raw head maps (list, one per level).  Every module's `backward` launches its HIP
+        adjoint kernels and fills `.grad` of its parameters (overwrite semantics); gradients of tensors with several
+        consumers (the save-list) are summed with the HIP add kernel."""
+        n = len(self.model)
+        pend = {n - 1: head_grads}
+        for m in reversed(list(self.model)):
+            g = pend.pop(m.i, None)
+            if g is None:
+                continue
+            if not hasattr(m, 'backward'):
+                raise NotImplementedError(f'{type(m).__name__}.backward is not built yet (training path of this module: next)')
+            first = m.i == 0
+            gin = m.backward(g, need_dx=False) if (first and isinstance(m, Conv)) else m.backward(g)
+            srcs = [m.f] if isinstance(m.f, int) else list(m.f)
+            gins = [gin] if isinstance(m.f, int) else list(gin)
+            for f, gi in zip(srcs, gins):
+                if gi is None:
+                    continue
+                j = m.i - 1 if f == -1 else (f if f >= 0 else m.i + f)
+                if j < 0:
+                    continue                      # gradient w.r.t. the image: not needed
+                if j in pend:
+                    dst = pend[j] if (pend[j].is_contiguous(memory_format=torch.channels_last) and pend[j].shape == gi.shape) else None
+                    pend[j] = ops.add(pend[j], gi, out=dst) if dst is not None else ops.add(pend[j], gi)
+                else:
+                    pend[j] = gi
+
     def fuse(self, verbose=True):
         """Fold BatchNorm into the conv parameters and drop the bn modules (tasks.py:121-146)."""
         if not self.is_fused():

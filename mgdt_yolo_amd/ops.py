@@ -307,3 +307,64 @@ def detect_loss_bwd(st, gscale=1.0):
             float(st.gains[0]), float(st.gains[1]), float(st.gains[2]), float(gscale), ptr(st.out5), ptr(st.ws), st.ws_bytes,
             dtype_code(st.feats[0].dtype), stream())
     return grads
+
+
+# ------------------------------------------------------------------ training side (BN batch stats, backward kernels)
+def _red_ws(c, dev):
+    return torch.empty(L.lib().mgdt_reduce_workspace_bytes(c), dtype=torch.uint8, device=dev)
+
+
+def bn_stats(y, eps, momentum, running_mean=None, running_var=None):
+    """Batch mean / rstd (biased variance) of an NHWC map; updates the running stats in place when given."""
+    c = y.shape[1]
+    mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=y.device)
+    ws = _red_ws(c, y.device)
+    _launch('bn_stats_fwd', 'mgdt_bn_stats_fwd', vp(y), float(eps), float(momentum), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+            ptr(ws), dtype_code(y.dtype), stream())
+    return mean, rstd
+
+
+def bn_act(y, mean, rstd, gamma, beta, act, out=None, r1=None, r2=None):
+    out = torch.empty_like(y) if out is None else out
+    _launch('bn_act_fwd', 'mgdt_bn_act_fwd', vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, vp(r1), vp(r2), vp(out), dtype_code(y.dtype), stream())
+    return out
+
+
+def bn_act_bwd(gz, y, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None):
+    """Returns dy (NHWC, same dtype); writes dgamma/dbeta (fp32) when given."""
+    dy = torch.empty_like(y)
+    ws = _red_ws(y.shape[1], y.device)
+    _launch('bn_act_bwd', 'mgdt_bn_act_bwd', vp(gz), vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(dgamma), ptr(dbeta), vp(dy), ptr(ws),
+            dtype_code(y.dtype), stream())
+    return dy
+
+
+def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
+    _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
+    return dx
+
+
+def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
+    lib = L.lib()
+    ws = torch.empty(lib.mgdt_conv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k), dtype=torch.uint8, device=x.device)
+    _launch('conv_wgrad', 'mgdt_conv_wgrad', vp(x), vp(x2), vp(dy), k, stride, ptr(dw), ptr(dbias), int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _launch('add_fwd', 'mgdt_add_fwd', vp(a), vp(b), vp(out), dtype_code(a.dtype), stream())
+    return out
+
+
+def maxpool5_bwd(x, gy):
+    """Adjoint of MaxPool2d(5,1,2): dense fp32 NHWC gradient (B,C,H,W channels_last)."""
+    b, c, h, w = x.shape
+    gx = torch.zeros((b, c, h, w), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    _launch('maxpool5_bwd', 'mgdt_maxpool5_bwd', vp(x), vp(gy), ptr(gx), dtype_code(x.dtype), stream())
+    return gx
+
+
+def nearest_bwd(gy, gx):
+    _launch('nearest_bwd', 'mgdt_nearest_bwd', vp(gy), vp(gx), dtype_code(gy.dtype), stream())
+    return gx

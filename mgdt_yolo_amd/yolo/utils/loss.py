@@ -75,3 +75,15 @@ class v8DetectionLoss:
             total, out5 = st.out5[0], st.out5
         self.epoch += 1
         return total, out5[1:4].detach()
+
+
+def loss_and_head_grads(crit, feats, batch, gscale=1.0):
+    """(loss*B, items[3], [d(loss*B)/d feats]) without torch.autograd: the entry the explicit backward pass starts from."""
+    feats = list(feats)
+    b = feats[0].shape[0]
+    imgsz = (feats[0].shape[2] * crit.stride_list[0], feats[0].shape[3] * crit.stride_list[0])
+    gt = crit.preprocess(batch, b, imgsz)
+    st = ops.detect_loss_fwd(feats, crit.stride_list, crit.reg_max, crit.nc, gt, crit.epoch, (crit.hyp.box, crit.hyp.cls, crit.hyp.dfl))
+    grads = ops.detect_loss_bwd(st, gscale)
+    crit.epoch += 1
+    return st.out5[0], st.out5[1:4], grads

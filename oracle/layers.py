@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-3  # yolo/utils/torch_utils.py:254-256 (initialize_weights overrides BatchNorm2d.eps)
+BN_TRAIN = False  # tests flip this to restate Conv.forward in training mode (batch statistics, conv.py:36-38)
 
 
 # ----------------------------------------------------------------------------- a1: Conv
@@ -43,6 +44,9 @@ def conv(x, sd, p, s=1, act='silu', fused=False, g=1):
         w2, b2 = fold_bn(sd, p)
         return _act(F.conv2d(x, w2.to(x.dtype), b2.to(x.dtype), s, k // 2, 1, g), act)
     y = F.conv2d(x, w.to(x.dtype), None, s, k // 2, 1, g)
+    if BN_TRAIN:
+        y = F.batch_norm(y, None, None, sd[p + '.bn.weight'].to(x.dtype), sd[p + '.bn.bias'].to(x.dtype), True, 0.0, BN_EPS)
+        return _act(y, act)
     y = F.batch_norm(y, sd[p + '.bn.running_mean'].to(x.dtype), sd[p + '.bn.running_var'].to(x.dtype),
                      sd[p + '.bn.weight'].to(x.dtype), sd[p + '.bn.bias'].to(x.dtype), False, 0.0, BN_EPS)
     return _act(y, act)

@@ -324,3 +324,56 @@ def test_model_loss_call_surface():
     batch = {'img': seeded_images(2, 160, 160, seed=1).to(DEV), **{k: v for k, v in GI.loss_inputs(1, 2, 4, 4, (20, 20))[1].items()}}
     total, items = m(batch)
     assert total.ndim == 0 and items.shape == (3,) and torch.isfinite(total) and (items >= 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ training step (fwd + bwd)
+def _oracle_train_grads(name, nc, x, lab, strides):
+    """CPU autograd through the oracle in training mode (BN batch statistics) -> loss, feats, {param name: grad}."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from oracle import layers as OL
+    from oracle import loss as OLoss
+    cfg = get_config(name, 'n', nc)
+    m = seed_state_dict_(DetectionModel(cfg, verbose=False), 0)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k and 'dfl' not in k) for k, v in m.state_dict().items()}
+    OL.BN_TRAIN = True
+    try:
+        feats = OL.model_forward(cfg, sd, x, strides, decode=False)
+        total, items, _ = OLoss.detection_loss(feats, lab, strides, 4, nc, call_count=0)
+        total.backward()
+    finally:
+        OL.BN_TRAIN = False
+    return total.detach(), [f.detach() for f in feats], {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize('name', ['yolov8'])
+def test_train_step_gradients_match_cpu_autograd(name):
+    """Train-mode forward (batch-stat BN) + HIP loss + explicit HIP backward vs torch-CPU autograd through the oracle."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.utils.loss import loss_and_head_grads, v8DetectionLoss
+    nc, B, S = 4, 2, 64
+    x = seeded_images(B, S, S, seed=11)
+    lab = seeded_labels(B, nc, seed=4, max_boxes=4, min_boxes=2)
+    lab['bboxes'][:, 2:] = lab['bboxes'][:, 2:] * 0.5 + 0.1
+    m = seed_state_dict_(DetectionModel(get_config(name, 'n', nc), verbose=False), 0).to(DEV).train()
+    strides = [float(s) for s in m.stride.tolist()]
+    ref_total, ref_feats, ref_grads = _oracle_train_grads(name, nc, x, lab, strides)
+    feats = m(x.to(DEV))
+    for f, r in zip(feats, ref_feats):
+        np.testing.assert_allclose(to_nchw(f), r.numpy(), atol=2e-4, rtol=2e-4)
+    total, items, hg = loss_and_head_grads(v8DetectionLoss(m), feats, lab)
+    np.testing.assert_allclose(total.item(), ref_total.item(), rtol=1e-4)
+    m.backward(hg)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if k not in ref_grads:
+            continue
+        assert p.grad is not None, f'no gradient for {k}'
+        g, r = p.grad.detach().cpu().double(), ref_grads[k].double()
+        err = (g - r).norm().item() / max(r.norm().item(), 1e-6 * r.numel() ** 0.5)
+        worst = max(worst, err)
+        assert err < 2e-2, (k, err, r.norm().item())
+    print('worst relative grad error', worst)
+    # running statistics were updated with momentum 0.03 (biased batch mean, unbiased variance)
+    bn0 = m.model[0].bn
+    assert not torch.allclose(bn0.running_mean.cpu(), seed_state_dict_(DetectionModel(get_config(name, 'n', nc), verbose=False), 0).model[0].bn.running_mean)
