@@ -159,6 +159,26 @@ int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int
 int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, mgdt_stream s);
 int mgdt_nearest_bwd(const mgdt_view* gy, const mgdt_view* gx, int dtype, mgdt_stream s);
 
+/* adjoints of the MSPA pooling attention and GD-neck ops (block.py:209-399, spr_module.py, convnextv2.py:48-77, utils.py:145-182) */
+int mgdt_ew_binary(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int mode, int dtype, mgdt_stream s);
+int mgdt_channel_affine(const mgdt_view* x, const float* scale, const float* shift, const mgdt_view* y, int dtype, mgdt_stream s);
+size_t mgdt_nc_reduce_workspace_bytes(int n, int c);
+int mgdt_nc_reduce(const mgdt_view* a, const mgdt_view* b, float* out, void* ws, int dtype, mgdt_stream s);
+int mgdt_adaptive_avgpool_bwd(const mgdt_view* gy, const mgdt_view* gx, int accumulate, int dtype, mgdt_stream s);
+int mgdt_bilinear_bwd(const mgdt_view* gy, const mgdt_view* gx, int accumulate, int dtype, mgdt_stream s);
+size_t mgdt_spr_bwd_workspace_bytes(int n, int c, int groups);
+int mgdt_spr_bwd(const mgdt_view* gy, const float* pooled_partial, int splits, const float* attn, const float* dattn,
+                 const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+                 const mgdt_view* gx, float* param_grads, void* ws, int dtype, mgdt_stream s);
+int mgdt_dwconv7_ln_train_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                              float eps, const mgdt_view* y, const mgdt_view* u_out, int dtype, mgdt_stream s);
+size_t mgdt_dwconv7_ln_bwd_workspace_bytes(int c);
+int mgdt_dwconv7_ln_bwd(const mgdt_view* x, const mgdt_view* u, const mgdt_view* gy, const float* dw_w49c, const float* ln_w, float eps,
+                        const mgdt_view* du_tmp, const mgdt_view* dx, int accumulate_dx, float* d_dw_w, float* d_dw_b,
+                        float* d_ln_w, float* d_ln_b, void* ws, int dtype, mgdt_stream s);
+int mgdt_grn_bwd(const mgdt_view* g, const mgdt_view* t, const float* S, const float* A, const float* B, const float* gamma,
+                 const mgdt_view* dt, float* dgamma, float* dbeta, void* ws, int dtype, mgdt_stream s);
+
 #ifdef __cplusplus
 }
 #endif

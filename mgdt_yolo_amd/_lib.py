@@ -56,6 +56,18 @@ PROTOTYPES = {
     'mgdt_add_fwd': (_i, [VP, VP, VP, _i, _vp]),
     'mgdt_maxpool5_bwd': (_i, [VP, VP, _vp, _i, _vp]),
     'mgdt_nearest_bwd': (_i, [VP, VP, _i, _vp]),
+    'mgdt_ew_binary': (_i, [VP, VP, VP, _i, _i, _vp]),
+    'mgdt_channel_affine': (_i, [VP, _vp, _vp, VP, _i, _vp]),
+    'mgdt_nc_reduce_workspace_bytes': (_sz, [_i, _i]),
+    'mgdt_nc_reduce': (_i, [VP, VP, _vp, _vp, _i, _vp]),
+    'mgdt_adaptive_avgpool_bwd': (_i, [VP, VP, _i, _i, _vp]),
+    'mgdt_bilinear_bwd': (_i, [VP, VP, _i, _i, _vp]),
+    'mgdt_spr_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'mgdt_spr_bwd': (_i, [VP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, VP, _vp, _vp, _i, _vp]),
+    'mgdt_dwconv7_ln_train_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, VP, VP, _i, _vp]),
+    'mgdt_dwconv7_ln_bwd_workspace_bytes': (_sz, [_i]),
+    'mgdt_dwconv7_ln_bwd': (_i, [VP, VP, VP, _vp, _vp, _f, VP, VP, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mgdt_grn_bwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

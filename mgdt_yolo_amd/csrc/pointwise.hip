@@ -490,7 +490,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw,
                                                          const float* __restrict__ dw, const float* __restrict__ db,
                                                          const float* __restrict__ lw, const float* __restrict__ lb, float eps,
-                                                         T* __restrict__ y, long ysn, long ysh, long ysw, int N, int H, int W, int C) {
+                                                         T* __restrict__ y, long ysn, long ysh, long ysw, int N, int H, int W, int C,
+                                                         T* __restrict__ uo = nullptr, long usn = 0, long ush = 0, long usw = 0) {
   const int Q = C / 4, PPB = 256 / Q;
   const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
   const long M = (long)N * H * W;
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const T* __restrict__ x
       }
     }
   }
+  if (uo && active) store4<T>(uo + n * usn + oy * ush + ox * usw + q * 4, acc);   // training: keep the pre-LayerNorm map
   red[threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
   __syncthreads();
   float mean = 0.f;
@@ -541,15 +543,28 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const T* __restrict__ x
   }
 }
 
+static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, float eps,
+                           const mgdt_view* y, const mgdt_view* u, int dtype, mgdt_stream s);
 extern "C" int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                                    float eps, const mgdt_view* y, int dtype, mgdt_stream s) {
+  return dwconv7_ln_impl(x, dw_w, dw_b, ln_w, ln_b, eps, y, nullptr, dtype, s);
+}
+extern "C" int mgdt_dwconv7_ln_train_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                                         float eps, const mgdt_view* y, const mgdt_view* u_out, int dtype, mgdt_stream s) {
+  if (!view_ok(u_out) || !vec4_ok(u_out, dtype) || u_out->n != x->n || u_out->h != x->h || u_out->w != x->w || u_out->c != x->c)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "dwconv7_ln_train: u_out must be an NHWC view like x");
+  return dwconv7_ln_impl(x, dw_w, dw_b, ln_w, ln_b, eps, y, u_out, dtype, s);
+}
+static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, float eps,
+                           const mgdt_view* y, const mgdt_view* u, int dtype, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y) || !dw_w || !dw_b || !ln_w || !ln_b) MGDT_FAIL(MGDT_BAD_ARG, "dwconv7_ln: null/empty argument");
   if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c || x->c / 4 > 256)
     MGDT_FAIL(MGDT_BAD_SHAPE, "dwconv7_ln: matching NHWC views, c%%4==0, c<=1024");
   int Q = x->c / 4, PPB = 256 / Q;
   long M = (long)x->n * x->h * x->w;
   MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_kernel<T><<<cdiv(M, PPB), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps,
-                                                                                       (T*)y->p, y->sn, y->sh, y->sw, x->n, x->h, x->w, x->c)));
+                                                                                       (T*)y->p, y->sn, y->sh, y->sw, x->n, x->h, x->w, x->c,
+                                                                                       u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0)));
   MGDT_CHECK_LAUNCH("dwconv7_ln_fwd");
   return MGDT_OK;
 }

@@ -115,20 +115,56 @@ class MSPA_C2f(HipModule):
             raise RuntimeError('MSPA_C2f: only stride=1 is wired by parse_model and built here')
         b, _, h, w = x.shape
         wd, s, n = self.inwidth, self.nums, self.btnk_nums
+        train = self.training and hasattr(self.convs[0], 'bn')
+        run = (lambda m: m.train_fwd) if train else (lambda m: m.run)
         cat = ops.new_act(b, (s - 1 + n) * wd, h, w, self.convs[0].out_dtype(x), x.device)
         # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
-        self.convs[0].run(x[:, :wd], out=cat[:, :wd])
+        run(self.convs[0])(x[:, :wd], out=cat[:, :wd])
         for i in range(1, s - 1):
-            self.convs[i].run(cat[:, (i - 1) * wd:i * wd], x2=x[:, i * wd:(i + 1) * wd], out=cat[:, i * wd:(i + 1) * wd])
+            run(self.convs[i])(cat[:, (i - 1) * wd:i * wd], x2=x[:, i * wd:(i + 1) * wd], out=cat[:, i * wd:(i + 1) * wd])
         # last group: chained bottlenecks, each output kept (block.py:260-263)
         src, pending = cat[:, (s - 2) * wd:(s - 1) * wd], x[:, (s - 1) * wd:s * wd]
         for j, m in enumerate(self.bottleneck):
             dst = cat[:, (s - 1 + j) * wd:(s + j) * wd]
             m.run(src, out=dst, x2=pending)
             src, pending = dst, None
-        out = self.convs[s - 1].run(cat)
-        attn = self.attention.group_attention(out, s)            # softmax over the 4 groups, fp32 [B, C]
+        out = run(self.convs[s - 1])(cat)
+        at = self.attention
+        if train:
+            attn, part = ops.spr_attention_train(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
+            self.__dict__.setdefault('_ctx', []).append((out, attn, part, x.shape))
+        else:
+            attn = at.group_attention(out, s)                      # softmax over the 4 groups, fp32 [B, C]
         return ops.scale_channels(out, attn)
+
+    def backward(self, g):
+        out, attn, part, xshape = self._ctx.pop()
+        wd, s, n = self.inwidth, self.nums, self.btnk_nums
+        at = self.attention
+        dattn = ops.nc_reduce(g, out)                               # d/d attn[n,c] = sum_hw g*out
+        gout, pg = ops.spr_bwd(g, part, attn, dattn, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
+        cw = wd
+        hid = cw // 4
+        o1, o2, o3 = hid * 5 * cw, hid * 5 * cw + hid, hid * 5 * cw + hid + cw * hid
+        at.fc1.weight.grad = pg[:o1].view_as(at.fc1.weight).clone()
+        at.fc1.bias.grad = pg[o1:o2].clone()
+        at.fc2.weight.grad = pg[o2:o3].view_as(at.fc2.weight).clone()
+        at.fc2.bias.grad = pg[o3:].clone()
+        gcat = self.convs[s - 1].backward(gout)
+        gx = ops.new_act(xshape[0], xshape[1], xshape[2], xshape[3], g.dtype, g.device)
+        sl = lambda t, i: t[:, i * wd:(i + 1) * wd]
+        for j in reversed(range(n)):                                 # bottleneck j: slot s-2+j (+ pending for j == 0) -> slot s-1+j
+            gin = self.bottleneck[j].backward(sl(gcat, s - 1 + j))
+            dst = sl(gcat, s - 2 + j)
+            ops.add(dst, gin, out=dst)
+            if j == 0:
+                ops.copy(gin, sl(gx, s - 1))                        # the pending addend spx[s-1]
+        for i in reversed(range(1, s - 1)):                          # convs[i](slot i-1 + spx[i])
+            gi = self.convs[i].backward(sl(gcat, i), dx_out=sl(gx, i))
+            dst = sl(gcat, i - 1)
+            ops.add(dst, gi, out=dst)
+        self.convs[0].backward(sl(gcat, 0), dx_out=sl(gx, 0))
+        return gx
 
 
 class SPPF(HipModule):
@@ -192,6 +228,7 @@ class SimFusion_4in(nn.Module):
         x_l, x_m, x_s, x_n = x
         b, c, h, w = x_s.shape
         cs = [x_l.shape[1], x_m.shape[1], c, x_n.shape[1]]
+        self._shapes = [t.shape for t in x]
         out = ops.new_act(b, sum(cs), h, w, x_s.dtype, x_s.device)
         o = 0
         ops.adaptive_avgpool(x_l, out[:, o:o + cs[0]]); o += cs[0]
@@ -199,6 +236,13 @@ class SimFusion_4in(nn.Module):
         ops.copy(x_s, out[:, o:o + cs[2]]); o += cs[2]
         ops.bilinear(x_n, out[:, o:o + cs[3]])
         return out
+
+    def backward(self, g):
+        sh = self._shapes
+        mk = lambda i: ops.new_act(sh[i][0], sh[i][1], sh[i][2], sh[i][3], g.dtype, g.device)
+        c0, c1, c2 = sh[0][1], sh[0][1] + sh[1][1], sh[0][1] + sh[1][1] + sh[2][1]
+        return [ops.adaptive_avgpool_bwd(g[:, :c0], mk(0)), ops.adaptive_avgpool_bwd(g[:, c0:c1], mk(1)), g[:, c1:c2],
+                ops.bilinear_bwd(g[:, c2:], mk(3))]
 
 
 class SimFusion_3in(HipModule):
@@ -215,21 +259,34 @@ class SimFusion_3in(HipModule):
         b, _, h, w = x[1].shape
         oc = self.cv_fuse.conv.out_channels
         dt, dev = x[1].dtype, x[1].device
+        self._shapes = [t.shape for t in x]
         cat = ops.new_act(b, 3 * oc, h, w, dt, dev)
         # branch 0: adaptive avg-pool then (optional) 1x1 ReLU conv
         if isinstance(self.cv1, nn.Identity):
             ops.adaptive_avgpool(x[0], cat[:, :oc])
         else:
-            self.cv1.run(ops.adaptive_avgpool(x[0], ops.new_act(b, x[0].shape[1], h, w, dt, dev)), out=cat[:, :oc])
+            (self.cv1.train_fwd if (self.training and hasattr(self.cv1, 'bn')) else self.cv1.run)(
+                ops.adaptive_avgpool(x[0], ops.new_act(b, x[0].shape[1], h, w, dt, dev)), out=cat[:, :oc])
         if isinstance(self.cv2, nn.Identity):
             ops.copy(x[1], cat[:, oc:2 * oc])
         else:
-            self.cv2.run(x[1], out=cat[:, oc:2 * oc])
+            (self.cv2.train_fwd if (self.training and hasattr(self.cv2, 'bn')) else self.cv2.run)(x[1], out=cat[:, oc:2 * oc])
         if isinstance(self.cv3, nn.Identity):
             ops.bilinear(x[2], cat[:, 2 * oc:])
         else:
-            self.cv3.run(ops.bilinear(x[2], ops.new_act(b, x[2].shape[1], h, w, dt, dev)), out=cat[:, 2 * oc:])
-        return self.cv_fuse.run(cat)
+            (self.cv3.train_fwd if (self.training and hasattr(self.cv3, 'bn')) else self.cv3.run)(
+                ops.bilinear(x[2], ops.new_act(b, x[2].shape[1], h, w, dt, dev)), out=cat[:, 2 * oc:])
+        return self.cv_fuse(cat)
+
+    def backward(self, g):
+        oc = self.cv_fuse.conv.out_channels
+        sh = self._shapes
+        mk = lambda i: ops.new_act(sh[i][0], sh[i][1], sh[i][2], sh[i][3], g.dtype, g.device)
+        gcat = self.cv_fuse.backward(g)
+        g0 = gcat[:, :oc] if isinstance(self.cv1, nn.Identity) else self.cv1.backward(gcat[:, :oc])
+        g1 = gcat[:, oc:2 * oc] if isinstance(self.cv2, nn.Identity) else self.cv2.backward(gcat[:, oc:2 * oc])
+        g2 = gcat[:, 2 * oc:] if isinstance(self.cv3, nn.Identity) else self.cv3.backward(gcat[:, 2 * oc:])
+        return [ops.adaptive_avgpool_bwd(g0, mk(0)), g1, ops.bilinear_bwd(g2, mk(2))]
 
 
 class IFM(nn.Module):
@@ -242,6 +299,11 @@ class IFM(nn.Module):
 
     def forward(self, x):
         return self.conv(x)
+
+    def backward(self, g):
+        for m in reversed(list(self.conv)):
+            g = m.backward(g)
+        return g
 
 
 class h_sigmoid(nn.Module):
@@ -268,7 +330,35 @@ class InjectionMultiSum_Auto_pool(HipModule):
         x_l, x_g = x
         c0 = sum(self.global_inp[:self.flag])
         g = x_g[:, c0:c0 + self.global_inp[self.flag]]      # split(...)[flag] as a channel-slice view
-        local = self.local_embedding.run(x_l)
-        ga = self.global_act.run(g)
-        gf = self.global_embedding.run(g)
+        train = self.training and hasattr(self.local_embedding, 'bn')
+        f = (lambda m: m.train_fwd) if train else (lambda m: m.run)
+        local = f(self.local_embedding)(x_l)
+        ga = f(self.global_act)(g)
+        gf = f(self.global_embedding)(g)
+        if train:
+            self.__dict__.setdefault('_ctx', []).append((local, ga, x_g.shape, c0))
         return ops.inject(local, ga, gf)                    # pool vs up-sample branch chosen from the shapes (block.py:369)
+
+    def backward(self, g):
+        local, ga, gshape, c0 = self._ctx.pop()
+        b, c, h, w = local.shape
+        use_pool = h < ga.shape[2]
+        small = lambda: ops.new_act(ga.shape[0], ga.shape[1], ga.shape[2], ga.shape[3], g.dtype, g.device)
+        g_sig_up = ops.ew(g, local, ops.EW_MUL)                                     # d/d (resampled gate) = g * local
+        if use_pool:    # out = local * avgpool(ga) + avgpool(gf)   (no h_sigmoid on this branch, block.py:385-390)
+            sig_up = ops.adaptive_avgpool(ga, ops.new_act(b, c, h, w, g.dtype, g.device))
+            g_ga = ops.adaptive_avgpool_bwd(g_sig_up, small())
+            g_gf = ops.adaptive_avgpool_bwd(g, small())
+        else:           # out = local * bilinear(h_sigmoid(ga)) + bilinear(gf)
+            sig_up = ops.bilinear(ops.ew(ga, ga, ops.EW_HSIG), ops.new_act(b, c, h, w, g.dtype, g.device))
+            g_hs = ops.bilinear_bwd(g_sig_up, small())
+            g_ga = ops.ew(g_hs, ga, ops.EW_HSIG_GRAD, out=g_hs)
+            g_gf = ops.bilinear_bwd(g, small())
+        g_local = ops.ew(g, sig_up, ops.EW_MUL, out=sig_up)
+        gx_l = self.local_embedding.backward(g_local)
+        gx_g = torch.zeros(gshape, dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+        dst = gx_g[:, c0:c0 + self.global_inp[self.flag]]
+        ggf = self.global_embedding.backward(g_gf)           # note: reverse order of the forward pushes is irrelevant (distinct modules)
+        gga = self.global_act.backward(g_ga)
+        ops.add(ggf, gga, out=dst)
+        return [gx_l, gx_g]

@@ -111,15 +111,18 @@ class Conv(HipModule):
         mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
         pk = self._cached(('raw', dt, not mfma), [self.conv.weight],
                           lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma, groups=self.conv.groups))
-        y = ops.conv2d(x, pk, s, ops.ACT_NONE, x2=x2 if mfma else None)
+        if x2 is not None and not mfma:
+            raise RuntimeError('Conv.train_fwd: the fused pre-add needs the MFMA path (NHWC input, cin % 4 == 0)')
+        y = ops.conv2d(x, pk, s, ops.ACT_NONE, x2=x2)
         bn = self.bn
         mean, rstd = ops.bn_stats(y, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         z = ops.bn_act(y, mean, rstd, bn.weight, bn.bias, act_code(self.act), out=out, r1=r1, r2=r2)
         self.__dict__.setdefault('_ctx', []).append((x, x2, y, mean, rstd, k, s))
         return z
 
-    def backward(self, gz, need_dx=True):
-        """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx."""
+    def backward(self, gz, need_dx=True, dx_out=None):
+        """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx
+        (written into the view `dx_out` when given)."""
         x, x2, y, mean, rstd, k, s = self._ctx.pop()
         bn = self.bn
         bn.weight.grad = torch.empty_like(bn.weight)
@@ -129,7 +132,7 @@ class Conv(HipModule):
         ops.conv_wgrad(x, dy, k, s, self.conv.weight.grad, x2=x2)
         if not need_dx:
             return None
-        dx = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
+        dx = dx_out if dx_out is not None else ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
         return ops.conv_dgrad(dy, self.conv.weight, k, s, dx)
 
     def forward_fuse(self, x):

@@ -5,6 +5,7 @@
       (mgdt_grn_stats_fwd, mgdt_conv2d_fwd with in_scale/in_shift/r1)
 The reference permutes NCHW->NHWC->NCHW around the Linear layers; NHWC is the native layout here.
 """
+import torch
 import torch.nn as nn
 
 from ... import ops
@@ -27,6 +28,45 @@ class ConvNeXtV2_Block(HipModule):
         self.pwconv2 = nn.Linear(4 * dim, dim)
         self.drop_path = nn.Identity()
 
+    def backward(self, g):
+        x, u, t1, y1, t2, t3, S, pw1, pw2, dw, gb = self._ctx.pop()
+        dim = self.dwconv.in_channels
+        # pwconv2 (+ bias) on the GRN output t3, residual passes g straight through
+        self.pwconv2.weight.grad = torch.empty_like(self.pwconv2.weight)
+        self.pwconv2.bias.grad = torch.empty_like(self.pwconv2.bias)
+        ops.conv_wgrad(t3, g, 1, 1, self.pwconv2.weight.grad, dbias=self.pwconv2.bias.grad)
+        g3 = ops.conv_dgrad(g, self.pwconv2.weight, 1, 1, torch.empty_like(t3))
+        # GRN
+        self.grn.gamma.grad = torch.empty_like(self.grn.gamma)
+        self.grn.beta.grad = torch.empty_like(self.grn.beta)
+        g2 = ops.grn_bwd(g3, t2, S, ops.nc_reduce(g3, t2), ops.nc_reduce(g3), gb[0], self.grn.gamma.grad, self.grn.beta.grad)
+        # GELU + pwconv1 bias: plain (no-BN) mode of the BN backward kernel, beta = bias
+        self.pwconv1.bias.grad = torch.empty_like(self.pwconv1.bias)
+        gy1 = ops.bn_act_bwd(g2, y1, None, None, None, self.pwconv1.bias, ops.ACT_GELU, None, self.pwconv1.bias.grad)
+        self.pwconv1.weight.grad = torch.empty_like(self.pwconv1.weight)
+        ops.conv_wgrad(t1, gy1, 1, 1, self.pwconv1.weight.grad)
+        gt1 = ops.conv_dgrad(gy1, self.pwconv1.weight, 1, 1, torch.empty_like(t1))
+        # LayerNorm + depthwise 7x7
+        self.dwconv.weight.grad = torch.empty_like(self.dwconv.weight)
+        self.dwconv.bias.grad = torch.empty_like(self.dwconv.bias)
+        self.norm.weight.grad = torch.empty_like(self.norm.weight)
+        self.norm.bias.grad = torch.empty_like(self.norm.bias)
+        gx = ops.dwconv7_ln_bwd(x, u, gt1, dw, self.norm.weight, self.norm.eps, self.dwconv.weight.grad, self.dwconv.bias.grad,
+                                self.norm.weight.grad, self.norm.bias.grad)
+        return ops.add(gx, g, out=gx)
+
+    def _train_fwd(self, x, dw, pw1_raw, pw2, gb):
+        dim = self.dwconv.in_channels
+        t1, u = ops.dwconv7_ln_train(x, dw, self.dwconv.bias.detach().float(), self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.eps)
+        y1 = ops.conv2d(t1, pw1_raw, 1, ops.ACT_NONE)                                   # raw Linear output WITHOUT bias
+        t2 = ops.bn_act(y1, None, None, None, self.pwconv1.bias, ops.ACT_GELU)          # gelu(y1 + b1)
+        S = ops.nc_reduce(t2, t2)                                                       # sum_hw t2^2 (GRN statistic)
+        scale = ops.grn_scale(t2, gb[0])
+        t3 = ops.channel_affine(t2, scale, gb[1])
+        out = ops.conv2d(t3, pw2, 1, ops.ACT_NONE, r1=x)
+        self.__dict__.setdefault('_ctx', []).append((x, u, t1, y1, t2, t3, S, pw1_raw, pw2, dw, gb))
+        return out
+
     def forward(self, x):
         dt = x.dtype
         dim = self.dwconv.in_channels
@@ -38,6 +78,12 @@ class ConvNeXtV2_Block(HipModule):
                            lambda: ops.PackedConv(self.pwconv2.weight.detach().reshape(dim, 4 * dim, 1, 1), self.pwconv2.bias, None, 1, dt))
         gb = self._cached('grn', [self.grn.gamma, self.grn.beta],
                           lambda: (self.grn.gamma.detach().float().reshape(-1).contiguous(), self.grn.beta.detach().float().reshape(-1).contiguous()))
+        if self.training:
+            if dt != torch.float32:
+                raise NotImplementedError('training runs in float32 in this round')
+            pw1_raw = self._cached(('pw1raw', dt), [self.pwconv1.weight],
+                                   lambda: ops.PackedConv(self.pwconv1.weight.detach().reshape(4 * dim, dim, 1, 1), None, None, 1, dt))
+            return self._train_fwd(x, dw, pw1_raw, pw2, gb)
         t = ops.dwconv7_ln(x, dw, self.dwconv.bias.detach().float(), self.norm.weight.detach().float(), self.norm.bias.detach().float(),
                            self.norm.eps)
         t = ops.conv2d(t, pw1, 1, ops.ACT_GELU)

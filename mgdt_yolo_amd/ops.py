@@ -93,6 +93,11 @@ def is_nhwc(t):
     return t.stride(1) == 1
 
 
+def like(t):
+    """Dense NHWC buffer with t's shape/dtype (torch.empty_like would inherit a channel-slice view's odd strides)."""
+    return new_act(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.dtype, t.device)
+
+
 # ------------------------------------------------------------------ conv
 class PackedConv:
     """Caller-owned packed weights of one convolution (BN folded) for one compute dtype."""
@@ -172,7 +177,7 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
 
 
 def scale_channels(x, attn, out=None):
-    out = torch.empty_like(x) if out is None else out
+    out = like(x) if out is None else out
     _launch('scale_channels_fwd', 'mgdt_scale_channels_fwd', vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream())
     return out
 
@@ -205,7 +210,7 @@ def copy(x, out):
 
 # ------------------------------------------------------------------ ConvNeXtV2 pieces, Injection, Detect
 def dwconv7_ln(x, dw_w49c, dw_b, ln_w, ln_b, eps, out=None):
-    out = torch.empty_like(x) if out is None else out
+    out = like(x) if out is None else out
     _launch('dwconv7_ln_fwd', 'mgdt_dwconv7_ln_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), eps, vp(out), dtype_code(x.dtype),
                                         stream())
     return out
@@ -221,7 +226,7 @@ def grn_scale(t, gamma):
 
 
 def inject(local, ga, gf, out=None):
-    out = torch.empty_like(local) if out is None else out
+    out = like(local) if out is None else out
     _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())
     return out
 
@@ -299,7 +304,7 @@ def detect_loss_fwd(feats, strides, reg_max, nc, gt, call_count, gains, want_ass
 
 def detect_loss_bwd(st, gscale=1.0):
     """d(loss*B)/d feats for the state of a previous detect_loss_fwd; returns a list of NHWC grads."""
-    grads = [torch.empty_like(f) for f in st.feats]
+    grads = [like(f) for f in st.feats]
     arr, keep = _view_array(st.feats)
     garr, gkeep = _view_array(grads)
     sarr = (C.c_float * len(st.feats))(*st.strides.tolist())
@@ -326,14 +331,14 @@ def bn_stats(y, eps, momentum, running_mean=None, running_var=None):
 
 
 def bn_act(y, mean, rstd, gamma, beta, act, out=None, r1=None, r2=None):
-    out = torch.empty_like(y) if out is None else out
+    out = like(y) if out is None else out
     _launch('bn_act_fwd', 'mgdt_bn_act_fwd', vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, vp(r1), vp(r2), vp(out), dtype_code(y.dtype), stream())
     return out
 
 
 def bn_act_bwd(gz, y, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None):
     """Returns dy (NHWC, same dtype); writes dgamma/dbeta (fp32) when given."""
-    dy = torch.empty_like(y)
+    dy = like(y)
     ws = _red_ws(y.shape[1], y.device)
     _launch('bn_act_bwd', 'mgdt_bn_act_bwd', vp(gz), vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(dgamma), ptr(dbeta), vp(dy), ptr(ws),
             dtype_code(y.dtype), stream())
@@ -352,7 +357,7 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
 
 
 def add(a, b, out=None):
-    out = torch.empty_like(a) if out is None else out
+    out = like(a) if out is None else out
     _launch('add_fwd', 'mgdt_add_fwd', vp(a), vp(b), vp(out), dtype_code(a.dtype), stream())
     return out
 
@@ -368,3 +373,86 @@ def maxpool5_bwd(x, gy):
 def nearest_bwd(gy, gx):
     _launch('nearest_bwd', 'mgdt_nearest_bwd', vp(gy), vp(gx), dtype_code(gy.dtype), stream())
     return gx
+
+
+# ------------------------------------------------------------------ adjoints of the MSPA / GD-neck ops
+EW_MUL, EW_HSIG_GRAD, EW_MUL_HSIG, EW_HSIG = 0, 1, 2, 3
+
+
+def ew(a, b, mode, out=None):
+    out = like(a) if out is None else out
+    _launch('ew_binary', 'mgdt_ew_binary', vp(a), vp(b), vp(out), mode, dtype_code(a.dtype), stream())
+    return out
+
+
+def channel_affine(x, scale, shift, out=None):
+    out = like(x) if out is None else out
+    _launch('channel_affine', 'mgdt_channel_affine', vp(x), ptr(scale), ptr(shift), vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
+def nc_reduce(a, b=None):
+    """sum over (h, w) of a*b (or a) per (image, channel) -> fp32 [B, C]."""
+    n, c = a.shape[:2]
+    out = torch.empty(n, c, dtype=torch.float32, device=a.device)
+    ws = torch.empty(L.lib().mgdt_nc_reduce_workspace_bytes(n, c), dtype=torch.uint8, device=a.device)
+    _launch('nc_reduce', 'mgdt_nc_reduce', vp(a), vp(b), ptr(out), ptr(ws), dtype_code(a.dtype), stream())
+    return out
+
+
+def adaptive_avgpool_bwd(gy, gx, accumulate=False):
+    _launch('adaptive_avgpool_bwd', 'mgdt_adaptive_avgpool_bwd', vp(gy), vp(gx), int(accumulate), dtype_code(gy.dtype), stream())
+    return gx
+
+
+def bilinear_bwd(gy, gx, accumulate=False):
+    _launch('bilinear_bwd', 'mgdt_bilinear_bwd', vp(gy), vp(gx), int(accumulate), dtype_code(gy.dtype), stream())
+    return gx
+
+
+def spr_attention_train(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
+    """Like spr_attention but also returns the pooled partial sums needed by the backward."""
+    b, c, h, w = x.shape
+    part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
+    _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
+    attn = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn), stream())
+    return attn, part
+
+
+def spr_bwd(gy, part, attn, dattn, fc1_w, fc1_b, fc2_w, fc2_b, groups):
+    """Returns (grad w.r.t. the pre-scale map, flat fp32 param grads [dW1 | db1 | dW2 | db2])."""
+    b, c = gy.shape[:2]
+    lib = L.lib()
+    cw = c // groups
+    hid = cw // 4
+    pg = torch.empty(hid * 5 * cw + hid + cw * hid + cw, dtype=torch.float32, device=gy.device)
+    ws = torch.empty(lib.mgdt_spr_bwd_workspace_bytes(b, c, groups), dtype=torch.uint8, device=gy.device)
+    gx = like(gy)
+    _launch('spr_bwd', 'mgdt_spr_bwd', vp(gy), ptr(part), L.SPR_SPLITS, ptr(attn), ptr(dattn), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups,
+            vp(gx), ptr(pg), ptr(ws), dtype_code(gy.dtype), stream())
+    return gx, pg
+
+
+def dwconv7_ln_train(x, dw_w49c, dw_b, ln_w, ln_b, eps):
+    y, u = like(x), like(x)
+    _launch('dwconv7_ln_train_fwd', 'mgdt_dwconv7_ln_train_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), eps, vp(y), vp(u),
+            dtype_code(x.dtype), stream())
+    return y, u
+
+
+def dwconv7_ln_bwd(x, u, gy, dw_w49c, ln_w, eps, d_dw_w, d_dw_b, d_ln_w, d_ln_b):
+    c = x.shape[1]
+    dx, tmp = like(x), like(x)
+    ws = torch.empty(L.lib().mgdt_dwconv7_ln_bwd_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+    _launch('dwconv7_ln_bwd', 'mgdt_dwconv7_ln_bwd', vp(x), vp(u), vp(gy), ptr(dw_w49c), ptr(ln_w), eps, vp(tmp), vp(dx), 0, ptr(d_dw_w), ptr(d_dw_b),
+            ptr(d_ln_w), ptr(d_ln_b), ptr(ws), dtype_code(x.dtype), stream())
+    return dx
+
+
+def grn_bwd(g, t, S, A, B, gamma, dgamma, dbeta):
+    n, c = t.shape[:2]
+    dt = like(t)
+    ws = torch.empty(3 * n * c, dtype=torch.float32, device=t.device)
+    _launch('grn_bwd', 'mgdt_grn_bwd', vp(g), vp(t), ptr(S), ptr(A), ptr(B), ptr(gamma), vp(dt), ptr(dgamma), ptr(dbeta), ptr(ws), dtype_code(t.dtype), stream())
+    return dt

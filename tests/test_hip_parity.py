@@ -345,7 +345,7 @@ def _oracle_train_grads(name, nc, x, lab, strides):
     return total.detach(), [f.detach() for f in feats], {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
 
 
-@pytest.mark.parametrize('name', ['yolov8'])
+@pytest.mark.parametrize('name', ['yolov8', 'mspa_c2f_gd_yolov8'])
 def test_train_step_gradients_match_cpu_autograd(name):
     """Train-mode forward (batch-stat BN) + HIP loss + explicit HIP backward vs torch-CPU autograd through the oracle."""
     from mgdt_yolo_amd.nn.tasks import DetectionModel
@@ -377,3 +377,45 @@ def test_train_step_gradients_match_cpu_autograd(name):
     # running statistics were updated with momentum 0.03 (biased batch mean, unbiased variance)
     bn0 = m.model[0].bn
     assert not torch.allclose(bn0.running_mean.cpu(), seed_state_dict_(DetectionModel(get_config(name, 'n', nc), verbose=False), 0).model[0].bn.running_mean)
+
+
+TRAIN_MODULE_CASES = ['conv3s1', 'c2f', 'c2f_sc', 'sppf', 'mspa_n1', 'mspa_n2_odd', 'mspa_n2_nosc', 'fam4', 'fam4_odd', 'laf3', 'laf3_allconv', 'ifm',
+                      'inject_up', 'inject_up_odd', 'inject_pool']
+
+
+@pytest.mark.parametrize('name', TRAIN_MODULE_CASES)
+def test_module_backward_matches_cpu_autograd(name):
+    """Training-mode forward + explicit HIP backward of one registry module vs torch-CPU autograd through the oracle
+    (BN batch statistics): output, input gradients and every parameter gradient."""
+    from oracle import layers as OL
+    cls, args, _ = GI.MODULE_CASES[name]
+    m = _make_module(cls, args).train()
+    xs_cpu = [x.clone().requires_grad_(True) for x in GI.module_inputs(name)]
+    sd = {'m.' + k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k) for k, v in m.state_dict().items()}
+    from test_oracle_golden import _oracle_module
+    OL.BN_TRAIN = True
+    try:
+        y_ref = _oracle_module(name, cls, args, sd, xs_cpu)
+        gy = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(y_ref.shape)).astype(np.float32))
+        (y_ref * gy).sum().backward()
+    finally:
+        OL.BN_TRAIN = False
+    xs = [x.detach().to(DEV).contiguous(memory_format=torch.channels_last) for x in xs_cpu]
+    y = m(xs[0] if len(xs) == 1 else xs)
+    np.testing.assert_allclose(to_nchw(y), y_ref.detach().numpy(), atol=2e-4, rtol=2e-4)
+    gin = m.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+    gin = gin if isinstance(gin, (list, tuple)) else [gin]
+    rel = lambda a, b: (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-7 * b.numel() ** 0.5)
+    for i, (g, xr) in enumerate(zip(gin, xs_cpu)):
+        assert rel(g.float().cpu().contiguous(), xr.grad) < 2e-3, (name, 'input', i, rel(g.float().cpu().contiguous(), xr.grad))
+    refs = {k: sd['m.' + k].grad for k, _ in m.named_parameters() if sd['m.' + k].grad is not None}
+    gscale = float(np.median([r.abs().max().item() for r in refs.values()])) if refs else 1.0
+    for k, p in m.named_parameters():
+        if k not in refs:
+            continue
+        r = refs[k]
+        assert p.grad is not None, (name, k)
+        # gradients that are analytically zero (e.g. a bias in front of a batch-norm) are pure rounding noise on both sides:
+        # the error is measured against max(|r|, 1% of the module's typical gradient magnitude)
+        err = (p.grad.cpu().double() - r.double()).abs().max().item() / max(r.abs().max().item(), 1e-2 * gscale)
+        assert err < 5e-3, (name, k, err)
