@@ -146,10 +146,8 @@ class MSPA_C2f(HipModule):
         cw = wd
         hid = cw // 4
         o1, o2, o3 = hid * 5 * cw, hid * 5 * cw + hid, hid * 5 * cw + hid + cw * hid
-        at.fc1.weight.grad = pg[:o1].view_as(at.fc1.weight).clone()
-        at.fc1.bias.grad = pg[o1:o2].clone()
-        at.fc2.weight.grad = pg[o2:o3].view_as(at.fc2.weight).clone()
-        at.fc2.bias.grad = pg[o3:].clone()
+        for prm, seg in ((at.fc1.weight, pg[:o1]), (at.fc1.bias, pg[o1:o2]), (at.fc2.weight, pg[o2:o3]), (at.fc2.bias, pg[o3:])):
+            ops.grad_buf(prm).copy_(seg.view_as(prm))       # four tiny device-to-device copies into the (flat) gradient buffer
         gcat = self.convs[s - 1].backward(gout)
         gx = ops.new_act(xshape[0], xshape[1], xshape[2], xshape[3], g.dtype, g.device)
         sl = lambda t, i: t[:, i * wd:(i + 1) * wd]

@@ -125,10 +125,10 @@ class Conv(HipModule):
         (written into the view `dx_out` when given)."""
         x, x2, y, mean, rstd, k, s = self._ctx.pop()
         bn = self.bn
-        bn.weight.grad = torch.empty_like(bn.weight)
-        bn.bias.grad = torch.empty_like(bn.bias)
+        ops.grad_buf(bn.weight)
+        ops.grad_buf(bn.bias)
         dy = ops.bn_act_bwd(gz, y, mean, rstd, bn.weight, bn.bias, act_code(self.act), bn.weight.grad, bn.bias.grad)
-        self.conv.weight.grad = torch.empty_like(self.conv.weight)
+        ops.grad_buf(self.conv.weight)
         ops.conv_wgrad(x, dy, k, s, self.conv.weight.grad, x2=x2)
         if not need_dx:
             return None

@@ -32,25 +32,25 @@ class ConvNeXtV2_Block(HipModule):
         x, u, t1, y1, t2, t3, S, pw1, pw2, dw, gb = self._ctx.pop()
         dim = self.dwconv.in_channels
         # pwconv2 (+ bias) on the GRN output t3, residual passes g straight through
-        self.pwconv2.weight.grad = torch.empty_like(self.pwconv2.weight)
-        self.pwconv2.bias.grad = torch.empty_like(self.pwconv2.bias)
+        ops.grad_buf(self.pwconv2.weight)
+        ops.grad_buf(self.pwconv2.bias)
         ops.conv_wgrad(t3, g, 1, 1, self.pwconv2.weight.grad, dbias=self.pwconv2.bias.grad)
         g3 = ops.conv_dgrad(g, self.pwconv2.weight, 1, 1, torch.empty_like(t3))
         # GRN
-        self.grn.gamma.grad = torch.empty_like(self.grn.gamma)
-        self.grn.beta.grad = torch.empty_like(self.grn.beta)
+        ops.grad_buf(self.grn.gamma)
+        ops.grad_buf(self.grn.beta)
         g2 = ops.grn_bwd(g3, t2, S, ops.nc_reduce(g3, t2), ops.nc_reduce(g3), gb[0], self.grn.gamma.grad, self.grn.beta.grad)
         # GELU + pwconv1 bias: plain (no-BN) mode of the BN backward kernel, beta = bias
-        self.pwconv1.bias.grad = torch.empty_like(self.pwconv1.bias)
+        ops.grad_buf(self.pwconv1.bias)
         gy1 = ops.bn_act_bwd(g2, y1, None, None, None, self.pwconv1.bias, ops.ACT_GELU, None, self.pwconv1.bias.grad)
-        self.pwconv1.weight.grad = torch.empty_like(self.pwconv1.weight)
+        ops.grad_buf(self.pwconv1.weight)
         ops.conv_wgrad(t1, gy1, 1, 1, self.pwconv1.weight.grad)
         gt1 = ops.conv_dgrad(gy1, self.pwconv1.weight, 1, 1, torch.empty_like(t1))
         # LayerNorm + depthwise 7x7
-        self.dwconv.weight.grad = torch.empty_like(self.dwconv.weight)
-        self.dwconv.bias.grad = torch.empty_like(self.dwconv.bias)
-        self.norm.weight.grad = torch.empty_like(self.norm.weight)
-        self.norm.bias.grad = torch.empty_like(self.norm.bias)
+        ops.grad_buf(self.dwconv.weight)
+        ops.grad_buf(self.dwconv.bias)
+        ops.grad_buf(self.norm.weight)
+        ops.grad_buf(self.norm.bias)
         gx = ops.dwconv7_ln_bwd(x, u, gt1, dw, self.norm.weight, self.norm.eps, self.dwconv.weight.grad, self.dwconv.bias.grad,
                                 self.norm.weight.grad, self.norm.bias.grad)
         return ops.add(gx, g, out=gx)

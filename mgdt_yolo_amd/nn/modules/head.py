@@ -29,8 +29,8 @@ class _HeadConv(HipModule):
     @staticmethod
     def backward(conv, x, g):
         """Plain conv + bias: fills conv.weight.grad / conv.bias.grad, returns dx."""
-        conv.weight.grad = torch.empty_like(conv.weight)
-        conv.bias.grad = torch.empty_like(conv.bias)
+        ops.grad_buf(conv.weight)
+        ops.grad_buf(conv.bias)
         ops.conv_wgrad(x, g, 1, 1, conv.weight.grad, dbias=conv.bias.grad)
         dx = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.dtype, x.device)
         return ops.conv_dgrad(g, conv.weight, 1, 1, dx)

@@ -93,6 +93,13 @@ def is_nhwc(t):
     return t.stride(1) == 1
 
 
+def grad_buf(p):
+    """The gradient tensor of parameter p (allocated on first use; the trainer points it into its flat gradient buffer)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
 def like(t):
     """Dense NHWC buffer with t's shape/dtype (torch.empty_like would inherit a channel-slice view's odd strides)."""
     return new_act(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.dtype, t.device)
@@ -456,3 +463,20 @@ def grn_bwd(g, t, S, A, B, gamma, dgamma, dbeta):
     ws = torch.empty(3 * n * c, dtype=torch.float32, device=t.device)
     _launch('grn_bwd', 'mgdt_grn_bwd', vp(g), vp(t), ptr(S), ptr(A), ptr(B), ptr(gamma), vp(dt), ptr(dgamma), ptr(dbeta), ptr(ws), dtype_code(t.dtype), stream())
     return dt
+
+
+# ------------------------------------------------------------------ optimizer on the flat buffers
+def grad_clip_coef(flat_grad, max_norm):
+    """fp32[2] on device: {total gradient norm, clip coefficient} (no host sync)."""
+    out = torch.empty(2, dtype=torch.float32, device=flat_grad.device)
+    ws = torch.empty(L.lib().mgdt_grad_norm_workspace_bytes(), dtype=torch.uint8, device=flat_grad.device)
+    _launch('grad_clip_coef', 'mgdt_grad_clip_coef', ptr(flat_grad), flat_grad.numel(), float(max_norm), ptr(out), ptr(ws), stream())
+    return out
+
+
+def sgd_step(p, g, buf, wd, lr, momentum, nesterov, first, clip=None):
+    _launch('sgd_step', 'mgdt_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), float(lr), float(momentum), int(nesterov), int(first), ptr(clip), stream())
+
+
+def ema_update(ema, p, decay):
+    _launch('ema_update', 'mgdt_ema_update', ptr(ema), ptr(p), p.numel(), float(decay), stream())

@@ -36,3 +36,14 @@ def max_over_ranks(value, device='cpu'):
 def aggregate_throughput(units_per_rank, steps, elapsed_max, world):
     """Whole-job units/s: every rank processed `units_per_rank` per step, the job took the slowest rank's time."""
     return world * units_per_rank * steps / elapsed_max
+
+
+def all_reduce_mean_(flat):
+    """Gradient exchange of data-parallel training: ONE all-reduce (mean) over the flat gradient buffer.
+    No-op for a single process.  RCCL ('nccl') on GPUs; the CPU tests drive it with 'gloo'."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    return flat

@@ -419,3 +419,34 @@ def test_module_backward_matches_cpu_autograd(name):
         # the error is measured against max(|r|, 1% of the module's typical gradient magnitude)
         err = (p.grad.cpu().double() - r.double()).abs().max().item() / max(r.abs().max().item(), 1e-2 * gscale)
         assert err < 5e-3, (name, k, err)
+
+
+def test_optimizer_step_matches_torch_sgd_and_loss_decreases():
+    """clip(10) + SGD(nesterov, wd groups) + EMA on the flat buffer vs torch.optim.SGD on the same gradients; then a few steps."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    nc, B, S = 4, 4, 64
+    m = seed_state_dict_(DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', nc), verbose=False), 0).to(DEV)
+    tr = DetectionTrainer(m, lr0=0.01)
+    batch = dict(img=(seeded_images(B, S, S, seed=2) * 255).to(torch.uint8), **seeded_labels(B, nc, seed=6, max_boxes=4, min_boxes=2))
+    batch['bboxes'][:, 2:] = batch['bboxes'][:, 2:] * 0.5 + 0.1
+    trainable = [(k, p) for k, p in m.named_parameters() if p.requires_grad]       # dfl.conv.weight is frozen (block.py:46)
+    before = {k: p.detach().cpu().clone() for k, p in trainable}
+    l0, _ = tr.step(batch)
+    grads = {k: p.grad.detach().cpu().clone() for k, p in trainable}
+    # reference update on the CPU with torch's own SGD + clip_grad_norm_
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in before.items()}
+    for k, p in ref.items():
+        p.grad = grads[k].clone()
+    torch.nn.utils.clip_grad_norm_(list(ref.values()), 10.0)
+    decay = [p for k, p in ref.items() if k.endswith('.weight') and p.ndim > 1]
+    nodecay = [p for k, p in ref.items() if not (k.endswith('.weight') and p.ndim > 1)]
+    opt = torch.optim.SGD([{'params': decay, 'weight_decay': 5e-4}, {'params': nodecay, 'weight_decay': 0.0}], lr=0.01, momentum=0.937, nesterov=True)
+    opt.step()
+    for k, p in trainable:
+        np.testing.assert_allclose(p.detach().cpu().numpy(), ref[k].detach().numpy(), atol=1e-6, rtol=1e-5, err_msg=k)
+    losses = [l0.item()] + [tr.step(batch)[0].item() for _ in range(8)]
+    print('losses', [round(v, 2) for v in losses])
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
+    assert tr.state.steps == 9 and not torch.equal(tr.state.ema[:100], tr.state.data[:100])

@@ -139,3 +139,26 @@ def test_multi_rank_bench_path_gloo_world2():
     assert res[0][1] != res[1][1]                                         # different data per rank
     assert res[0][2] == res[1][2] == 1.5                                  # MAX over ranks
     assert res[0][3] == pytest.approx(2 * 32 * 10 / 1.5)                  # whole-job aggregate
+
+
+def _rank_allreduce(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from mgdt_yolo_amd import parallel
+    dist = parallel.init('gloo')
+    flat = torch.full((1000,), float(rank + 1))          # this rank's flat gradient buffer
+    parallel.all_reduce_mean_(flat)
+    q.put((rank, flat[0].item(), flat[-1].item()))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_gloo_world2():
+    """The training exchange step (one mean all-reduce over the flat gradient buffer) with 2 ranks on CPU/gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    ps = [ctx.Process(target=_rank_allreduce, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(30) for p in ps]
+    assert res == [(0, 1.5, 1.5), (1, 1.5, 1.5)]
