@@ -170,7 +170,7 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   size_t panel = (size_t)a.nchunks * NT * 1024;
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
-  size_t lds = a.tab_bytes + (size_t)a.seg_chunks * NT * 1024;
+  size_t lds = a.tab_bytes + (size_t)NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * 1024;
   int gx = std::min(a.numTiles, waves == 8 ? 512 : 1024), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
   if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, waves * 64, lds, st);

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int L = D - 1;             // look-ahead in (padded) steps
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint2* ptab = (uint2*)smem;          // per 16-byte K piece: {byte offset of (tap, channel) inside the x view, tap index}
-  char* wlds = smem + a.tab_bytes;
+  float* blds = (float*)(smem + a.tab_bytes);       // this workgroup's NT*16 bias values (read in every tile's epilogue)
+  char* wlds = smem + a.tab_bytes + NT * 16 * sizeof(float);
 
   const int nthr = blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     if (tap < a.KS * a.KS) e = make_uint2((uint32_t)(((tap / a.KS) * xsh + (tap % a.KS) * xsw + cp * PE) * (int)sizeof(T)), (uint32_t)tap);
     ptab[p] = e;
   }
+  if (tid < NT * 16) blds[tid] = a.bias[blockIdx.y * NT * 16 + tid];
   __syncthreads();
 
   auto stage = [&](int seg) __attribute__((always_inline)) {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
       for (int nt = 0; nt < NT; ++nt) {
         const int co = (nb0 + nt) * 16 + 4 * g;
         if (co >= a.Cout) continue;
-        const f32x4 b = *(const f32x4*)(a.bias + co);
+        const f32x4 b = *(const f32x4*)(blds + nt * 16 + 4 * g);
         f32x4 v = acc[nt][mt];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = actf(v[j] + b[j]);

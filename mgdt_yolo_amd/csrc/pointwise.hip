@@ -543,6 +543,110 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const T* __restrict__ x
   }
 }
 
+// LDS-tiled variant: one workgroup = an 8x8 output tile of one image x all channels.  The (8+6)x(8+6) input halo is staged
+// once in LDS (each input pixel is used by up to 49 outputs), a thread owns one channel quad and ~6 pixels, keeps one kernel
+// row of weights (7 x float4) in registers at a time; LayerNorm over the pixel's channels goes through LDS partials.
+#define DW_TH 8
+#define DW_TW 8
+template <typename T, int MAXP>
+__global__ __launch_bounds__(256) void dwconv7_ln_tiled_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw,
+                                                               const float* __restrict__ dw, const float* __restrict__ db,
+                                                               const float* __restrict__ lw, const float* __restrict__ lb, float eps,
+                                                               T* __restrict__ y, long ysn, long ysh, long ysw, int H, int W, int C,
+                                                               T* __restrict__ uo, long usn, long ush, long usw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+  const int Q = C / 4, PL = 256 / Q;                    // channel quads, pixel lanes
+  constexpr int HH = DW_TH + 6, HW_ = DW_TW + 6, NPIX = DW_TH * DW_TW;
+  T* halo = (T*)smem_dw;                                // [HH][HW_][C]
+  float* wl = (float*)(smem_dw + (((size_t)HH * HW_ * C * sizeof(T) + 15) & ~(size_t)15));   // [49][C]
+  float* red = wl + 49 * C;                             // [NPIX][Q] partial sums (reused for mean and variance)
+  const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
+  const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
+  const int ty0 = (tr / tiles_x) * DW_TH, tx0 = (tr % tiles_x) * DW_TW;
+  const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+  const bool live = pl < PL;
+  if (live)
+    for (int p = pl; p < HH * HW_; p += PL) {            // stage the halo (zero padding outside the image); q, pl fixed per thread
+      int hy = p / HW_, hx = p % HW_;
+      int iy = ty0 + hy - 3, ix = tx0 + hx - 3;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = load4<T>(x + n * xsn + iy * xsh + ix * xsw + q * 4);
+      store4<T>(halo + (long)p * C + q * 4, v);
+    }
+  for (int i = threadIdx.x; i < 49 * Q; i += 256) *(f32x4*)(wl + i * 4) = *(const f32x4*)(dw + i * 4);
+  __syncthreads();
+  f32x4 acc[MAXP];                                      // MAXP >= ceil(NPIX / PL) (host-selected instantiation)
+  if (live) {
+    const f32x4 bq = *(const f32x4*)(db + q * 4);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) acc[k] = bq;
+    for (int ky = 0; ky < 7; ++ky) {
+      f32x4 wr[7];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) wr[kx] = *(const f32x4*)(wl + (ky * 7 + kx) * C + q * 4);
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        int p = pl + k * PL;
+        if (p < NPIX) {
+          int py = p / DW_TW, px = p % DW_TW;
+          const T* hp = halo + ((long)(py + ky) * HW_ + px) * C + q * 4;
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) {
+            f32x4 v = load4<T>(hp + kx * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(v[j], wr[kx][j], acc[k][j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      int p = pl + k * PL;
+      if (p < NPIX) red[p * Q + q] = acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    }
+  }
+  __syncthreads();
+  float mean[MAXP];
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      int p = pl + k * PL;
+      mean[k] = 0.f;
+      if (p < NPIX) {
+        for (int j = 0; j < Q; ++j) mean[k] += red[p * Q + j];
+        mean[k] /= (float)C;
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      int p = pl + k * PL;
+      if (p < NPIX) {
+        f32x4 d = acc[k] - mean[k];
+        red[p * Q + q] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const f32x4 gq = *(const f32x4*)(lw + q * 4), bq2 = *(const f32x4*)(lb + q * 4);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      int p = pl + k * PL;
+      if (p >= NPIX) continue;
+      int oy = ty0 + p / DW_TW, ox = tx0 + p % DW_TW;
+      if (oy >= H || ox >= W) continue;
+      float var = 0.f;
+      for (int j = 0; j < Q; ++j) var += red[p * Q + j];
+      float rstd = 1.f / sqrtf(var / (float)C + eps);
+      if (uo) store4<T>(uo + n * usn + oy * ush + ox * usw + q * 4, acc[k]);
+      store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, (acc[k] - mean[k]) * rstd * gq + bq2);
+    }
+  }
+}
+
 static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, float eps,
                            const mgdt_view* y, const mgdt_view* u, int dtype, mgdt_stream s);
 extern "C" int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
@@ -560,6 +664,22 @@ static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* d
   if (!view_ok(x) || !view_ok(y) || !dw_w || !dw_b || !ln_w || !ln_b) MGDT_FAIL(MGDT_BAD_ARG, "dwconv7_ln: null/empty argument");
   if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c || x->c / 4 > 256)
     MGDT_FAIL(MGDT_BAD_SHAPE, "dwconv7_ln: matching NHWC views, c%%4==0, c<=1024");
+  {   // LDS-tiled fast path: channel quads divide the block and the halo + weights fit in 64 KiB
+    const int Qt = x->c / 4;
+    const size_t halo_b = ((size_t)(DW_TH + 6) * (DW_TW + 6) * x->c * dtype_size(dtype) + 15) & ~(size_t)15;
+    const size_t lds_t = halo_b + (size_t)49 * x->c * 4 + (size_t)DW_TH * DW_TW * Qt * 4;
+    if (Qt <= 64 && lds_t <= 64 * 1024) {
+      const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
+      const int need = cdiv(DW_TH * DW_TW, 256 / Qt);      // pixels per thread
+#define DWT_L(MP) MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_tiled_kernel<T, MP><<<x->n * tiles, 256, lds_t, (hipStream_t)s>>>( \
+                                     (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c, \
+                                     u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0)))
+      if (need <= 4) DWT_L(4); else if (need <= 7) DWT_L(7); else if (need <= 8) DWT_L(8); else DWT_L(16);
+#undef DWT_L
+      MGDT_CHECK_LAUNCH("dwconv7_ln_fwd(tiled)");
+      return MGDT_OK;
+    }
+  }
   int Q = x->c / 4, PPB = 256 / Q;
   long M = (long)x->n * x->h * x->w;
   MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_kernel<T><<<cdiv(M, PPB), 256, 0, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps,
