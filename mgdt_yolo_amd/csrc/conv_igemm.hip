@@ -166,12 +166,13 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
     if ((e = getenv("MGDT_CONV_WAVES"))) waves = atoi(e);
   }
   a.numTiles = cdiv(M, 16 * waves * MT);
+  a.T8 = cdiv(a.numTiles, 8);
   a.tab_bytes = (a.nchunks + 3) / 4 * 4 * 4 * 8;   // uint2 per piece, padded to a multiple of 4 chunks (>= nchp in the kernel)
   size_t panel = (size_t)a.nchunks * NT * 1024;
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
   size_t lds = a.tab_bytes + (size_t)NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * 1024;
-  int gx = std::min(a.numTiles, waves == 8 ? 512 : 1024), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
+  int gx = std::min(8 * a.T8, waves == 8 ? 512 : 1024), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
   if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, waves * 64, lds, st);
   return dispatch_igemm<bf16>(a, NT, MT, gx, gy, waves * 64, lds, st);

@@ -21,7 +21,7 @@ struct ConvArgs {
   const char* r2; long r2sn, r2sh, r2sw;
   int N, H, W, Cin, Ho, Wo, Cout;
   int KS, stride, pad, CP, nchunks, NTtot, act;
-  int M, HoWo, numTiles, seg_chunks, nseg, tab_bytes;
+  int M, HoWo, numTiles, T8, seg_chunks, nseg, tab_bytes;
   FastDiv fd_howo, fd_wo;
   uint32_t x_bytes, x2_bytes;   // addressable extent of the x / x2 views (buffer descriptor range)
 };
@@ -117,11 +117,15 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? a.x2_bytes : 0u, 0x00020000);
 
-  auto setup = [&](int tile, TileState(&S)[MT]) __attribute__((always_inline)) {
+  // v = position in the launch-wide round-robin; workgroups land on XCD (id % 8), so XCD k is given the CONTIGUOUS tile range
+  // [k*T8, (k+1)*T8): the halo rows a 3x3 tile shares with its neighbours are then served by that XCD's own L2.
+  auto setup = [&](int v, TileState(&S)[MT]) __attribute__((always_inline)) {
+    const int tile = (v & 7) * a.T8 + (v >> 3);
+    const bool tv = (v >> 3) < a.T8 && tile < a.numTiles;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       int m = tile * BM + (wave * MT + mt) * 16 + r;
-      const bool pv = tile < a.numTiles && m < a.M;
+      const bool pv = tv && m < a.M;
       int mm = pv ? m : 0;
       int n = (int)fdiv((uint32_t)mm, a.fd_howo), rem = mm - n * a.HoWo;
       int oy = (int)fdiv((uint32_t)rem, a.fd_wo), ox = rem - oy * a.Wo;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   const char* const wlane = wlds + lane * 16;
   constexpr bool multi = MULTI;   // weight panel staged in K segments (only when even one cout block does not fit in LDS)
 
-  for (; tile < a.numTiles; tile += gridDim.x) {
+  for (; tile < 8 * a.T8; tile += gridDim.x) {
     zero_acc();
     const uint2* tp = tab_g + 4 * L;             // table entry of the chunk that step 0 prefetches
     const char* wp = wlane;                      // weight blocks of the chunk that step 0 computes
