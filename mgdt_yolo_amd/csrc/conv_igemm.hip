@@ -104,7 +104,7 @@ template <typename T>
 static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, int threads, size_t lds, hipStream_t st) {
 #define CASE(nt, mt) \
   if (NT == nt && MT == mt) return launch_igemm<T, nt, mt>(a, gx, gy, threads, lds, st);
-  CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
+  CASE(1, 2) CASE(1, 4) CASE(1, 8) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
 #undef CASE
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: no kernel for NT=%d MT=%d", NT, MT);
 }
@@ -132,22 +132,31 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
 
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = (const char*)x->p; a.xsn = x->sn; a.xsh = x->sh; a.xsw = x->sw;
-  if (x2 && x2->p) { a.x2 = (const char*)x2->p; a.x2sn = x2->sn; a.x2sh = x2->sh; a.x2sw = x2->sw; }
+  const long sz = (long)dtype_size(dtype);
+  auto extent = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * sz; };
+  // every view is addressed through a 32-bit buffer descriptor: extents < 2 GiB, row / pixel strides < 8 MiB (24-bit multiplies)
+  bool fits = true;
+  auto bind = [&](const mgdt_view* v, const char** p, int* sn, int* sh, int* sw, uint32_t* bytes) {
+    if (!v || !v->p) return;
+    if (extent(v) >= 0x7fffffffL || v->sh * sz >= (1L << 23) || v->sw * sz >= (1L << 23)) { fits = false; return; }
+    *p = (const char*)v->p; *sn = (int)(v->sn * sz); *sh = (int)(v->sh * sz); *sw = (int)(v->sw * sz); *bytes = (uint32_t)extent(v);
+  };
+  const char* yp = nullptr;
+  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes);
+  bind(x2, &a.x2, &a.x2sn, &a.x2sh, &a.x2sw, &a.x2_bytes);
+  bind(y, &yp, &a.ysn, &a.ysh, &a.ysw, &a.y_bytes);
+  bind(r1, &a.r1, &a.r1sn, &a.r1sh, &a.r1sw, &a.r1_bytes);
+  bind(r2, &a.r2, &a.r2sn, &a.r2sh, &a.r2sw, &a.r2_bytes);
+  if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: a view spans >= 2 GiB or has a row stride >= 8 MiB");
+  a.y = (char*)yp;
   a.in_scale = in_scale; a.in_shift = in_shift;
   a.wpk = (const char*)packed_w; a.bias = bias;
-  a.y = (char*)y->p; a.ysn = y->sn; a.ysh = y->sh; a.ysw = y->sw;
-  if (r1 && r1->p) { a.r1 = (const char*)r1->p; a.r1sn = r1->sn; a.r1sh = r1->sh; a.r1sw = r1->sw; }
-  if (r2 && r2->p) { a.r2 = (const char*)r2->p; a.r2sn = r2->sn; a.r2sh = r2->sh; a.r2sw = r2->sw; }
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Ho = Ho; a.Wo = Wo; a.Cout = y->c;
   a.KS = k; a.stride = stride; a.pad = pad; a.act = act;
   conv_geometry(a.Cin, a.Cout, k, dtype, &a.CP, &a.nchunks, &a.NTtot);
   long M = (long)a.N * Ho * Wo;
-  if (M > 0x7fffffffL || (long)x->n * x->sn > 0x7fffffffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: problem too large");
+  if (M > 0x7fffffffL - (1 << 20)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: problem too large");
   a.M = (int)M; a.HoWo = Ho * Wo;
-  auto extent = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * (long)dtype_size(dtype); };
-  if (extent(x) >= 0x7fffffffL || (x2 && x2->p && extent(x2) >= 0x7fffffffL)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: input view spans >= 2 GiB");
-  a.x_bytes = (uint32_t)extent(x); a.x2_bytes = (x2 && x2->p) ? (uint32_t)extent(x2) : 0u;
   a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
 
   // tile choice: NT = cout blocks per workgroup - as many as divide NTtot and keep the whole weight panel in LDS
@@ -156,7 +165,8 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   int NT = 1;
   for (int c : {8, 6, 5, 4, 3, 2, 1})
     if (a.NTtot % c == 0 && a.nchunks * c <= LDS_PANEL_KIB) { NT = c; break; }
-  const int MT = 2;   // MT=2 with depth-4 prefetch measured faster than MT=4 on every layer of the target nets
+  int MT = 2;   // MT=2 with depth-4 prefetch measured faster than MT=4 on every wide layer of the target nets
+  if (NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e ? atoi(e) : 2; }
   int waves = 8;
   auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
   if (wgs(NT, waves) < 512) waves = 4;                              // small maps: more, smaller tiles
@@ -167,7 +177,7 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   }
   a.numTiles = cdiv(M, 16 * waves * MT);
   a.T8 = cdiv(a.numTiles, 8);
-  a.tab_bytes = (a.nchunks + 3) / 4 * 4 * 4 * 8;   // uint2 per piece, padded to a multiple of 4 chunks (>= nchp in the kernel)
+  a.tab_bytes = (a.nchunks + 3) / 4 * 4 * 4 * 16;   // uint4 per piece, padded to a multiple of 4 chunks (>= nchp in the kernel)
   size_t panel = (size_t)a.nchunks * NT * 1024;
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments

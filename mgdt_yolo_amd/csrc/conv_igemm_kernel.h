@@ -11,19 +11,19 @@ template <typename T> struct Piece;
 template <> struct Piece<float> { static constexpr int PE = 4; typedef f32x4 frag; };
 template <> struct Piece<bf16> { static constexpr int PE = 8; typedef bf16x8 frag; };
 
-struct ConvArgs {
-  const char* x; long xsn, xsh, xsw;
-  const char* x2; long x2sn, x2sh, x2sw;
+struct ConvArgs {   // all strides / offsets in BYTES and < 2 GiB (host-checked): the kernel addresses through buffer descriptors
+  const char* x; int xsn, xsh, xsw;
+  const char* x2; int x2sn, x2sh, x2sw;
   const float* in_scale; const float* in_shift;
   const char* wpk; const float* bias;
-  char* y; long ysn, ysh, ysw;
-  const char* r1; long r1sn, r1sh, r1sw;
-  const char* r2; long r2sn, r2sh, r2sw;
+  char* y; int ysn, ysh, ysw;
+  const char* r1; int r1sn, r1sh, r1sw;
+  const char* r2; int r2sn, r2sh, r2sw;
   int N, H, W, Cin, Ho, Wo, Cout;
   int KS, stride, pad, CP, nchunks, NTtot, act;
   int M, HoWo, numTiles, T8, seg_chunks, nseg, tab_bytes;
   FastDiv fd_howo, fd_wo;
-  uint32_t x_bytes, x2_bytes;   // addressable extent of the x / x2 views (buffer descriptor range)
+  uint32_t x_bytes, x2_bytes, y_bytes, r1_bytes, r2_bytes;   // addressable extents of the views (buffer descriptor ranges)
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -57,6 +57,26 @@ __device__ __forceinline__ typename Piece<T>::frag frag_affine(typename Piece<T>
   return o;
 }
 
+// 4 consecutive channels through a bounds-checked descriptor (out-of-range: loads give 0, stores are dropped)
+template <typename T> __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rs, uint32_t off);
+template <> __device__ __forceinline__ f32x4 bload4<float>(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+template <> __device__ __forceinline__ f32x4 bload4<bf16>(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+  const bf16x4 o = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+  return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+}
+template <typename T> __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t rs, uint32_t off, f32x4 v);
+template <> __device__ __forceinline__ void bstore4<float>(__amdgpu_buffer_rsrc_t rs, uint32_t off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, off, 0, 0);
+}
+template <> __device__ __forceinline__ void bstore4<bf16>(__amdgpu_buffer_rsrc_t rs, uint32_t off, f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, o), rs, off, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 mma(f32x4 w, f32x4 p, f32x4 acc) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], p[s], acc, 0, 0, 0);
@@ -74,30 +94,35 @@ __device__ __forceinline__ f32x4 mma(bf16x8 w, bf16x8 p, f32x4 acc) {
 // runs its epilogue.  The step body is a handful of integer instructions: one 8-byte table read, per row block a bit test
 // on the pixel's tap-validity mask + one add, a bounds-checked buffer load (zero fill for padding), NT ds_read_b128 at
 // immediate offsets from a running LDS pointer, NT*MT MFMAs.
-struct TileState { int xo; uint32_t vm; long yo; int pn, iy0, ix0; };
+struct TileState { int xo; uint32_t vm; int yo, x2o, r1o, r2o, pn; };   // byte offsets; MGDT_OOB = "no such pixel"
+#define MGDT_OOB ((int)0x80000000)   // >= every view extent, and stays out of range after a (small) channel offset is added
 
 template <typename T, int NT, int MT, int D, bool EXTRA, bool MULTI>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   typedef typename Piece<T>::frag frag;
   constexpr int PE = Piece<T>::PE;
   constexpr int L = D - 1;             // look-ahead in (padded) steps
+  constexpr int SZ = (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint2* ptab = (uint2*)smem;          // per 16-byte K piece: {byte offset of (tap, channel) inside the x view, tap index}
-  float* blds = (float*)(smem + a.tab_bytes);       // this workgroup's NT*16 bias values (read in every tile's epilogue)
+  uint4* ptab = (uint4*)smem;          // per 16-byte K piece: {byte offset of (tap, channel) in the x view, tap, byte offset in the x2 view, channel}
+  float* blds = (float*)(smem + a.tab_bytes);       // this workgroup's NT*16 bias values (accumulators start from them)
   char* wlds = smem + a.tab_bytes + NT * 16 * sizeof(float);
 
   const int nthr = blockDim.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the tile arithmetic below runs on the scalar unit
   const int r = lane & 15, g = lane >> 4;
   const int nb0 = blockIdx.y * NT;
   const int BM = (nthr >> 6) * MT * 16;
-  const int xsn = (int)a.xsn, xsh = (int)a.xsh, xsw = (int)a.xsw;
   const int nchp = (a.nchunks + D - 1) / D * D;
 
   for (int p = tid; p < nchp * 4; p += nthr) {   // table padded to nchp chunks: padding pieces carry tap 31 (never valid)
     int tap = p / a.CP, cp = p % a.CP;
-    uint2 e = make_uint2(0u, 31u);
-    if (tap < a.KS * a.KS) e = make_uint2((uint32_t)(((tap / a.KS) * xsh + (tap % a.KS) * xsw + cp * PE) * (int)sizeof(T)), (uint32_t)tap);
+    uint4 e = make_uint4(0u, 31u, 0u, 0u);
+    if (tap < a.KS * a.KS) {
+      const int dy = tap / a.KS, dx = tap % a.KS;
+      e = make_uint4((uint32_t)(dy * a.xsh + dx * a.xsw + cp * PE * SZ), (uint32_t)tap, (uint32_t)(dy * a.x2sh + dx * a.x2sw + cp * PE * SZ), (uint32_t)(cp * PE));
+    }
     ptab[p] = e;
   }
   if (tid < NT * 16) blds[tid] = a.bias[blockIdx.y * NT * 16 + tid];
@@ -116,32 +141,51 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   };
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? a.x2_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.r1 ? a.r1 : a.x), 0, a.r1 ? a.r1_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.r2 ? a.r2 : a.x), 0, a.r2 ? a.r2_bytes : 0u, 0x00020000);
 
   // v = position in the launch-wide round-robin; workgroups land on XCD (id % 8), so XCD k is given the CONTIGUOUS tile range
   // [k*T8, (k+1)*T8): the halo rows a 3x3 tile shares with its neighbours are then served by that XCD's own L2.
+  // The 16 pixels of a row block are consecutive output positions: their first pixel is decomposed on the scalar unit, the
+  // lanes add their index and wrap (one row / one image at most when Wo >= 16), so no per-lane division or 32-bit multiply.
   auto setup = [&](int v, TileState(&S)[MT]) __attribute__((always_inline)) {
     const int tile = (v & 7) * a.T8 + (v >> 3);
     const bool tv = (v >> 3) < a.T8 && tile < a.numTiles;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      int m = tile * BM + (wave * MT + mt) * 16 + r;
-      const bool pv = tv && m < a.M;
-      int mm = pv ? m : 0;
-      int n = (int)fdiv((uint32_t)mm, a.fd_howo), rem = mm - n * a.HoWo;
-      int oy = (int)fdiv((uint32_t)rem, a.fd_wo), ox = rem - oy * a.Wo;
+      const int m0 = tv ? tile * BM + (wave * MT + mt) * 16 : 0;   // uniform
+      const bool pv = tv && m0 + r < a.M;
+      int n, oy, ox;
+      if (a.Wo >= 16) {
+        const int n0 = (int)fdiv((uint32_t)m0, a.fd_howo), rem = m0 - n0 * a.HoWo;
+        const int oy0 = (int)fdiv((uint32_t)rem, a.fd_wo), ox0 = rem - oy0 * a.Wo;
+        n = n0; oy = oy0; ox = ox0 + r;
+        if (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+        if (oy >= a.Ho) { oy = 0; ++n; }
+      } else {
+        const int mm = pv ? m0 + r : 0;
+        n = (int)fdiv((uint32_t)mm, a.fd_howo);
+        const int rem = mm - n * a.HoWo;
+        oy = (int)fdiv((uint32_t)rem, a.fd_wo); ox = rem - oy * a.Wo;
+      }
       TileState t;
       t.pn = n;
-      t.iy0 = oy * a.stride - a.pad;
-      t.ix0 = ox * a.stride - a.pad;
-      t.xo = (n * xsn + t.iy0 * xsh + t.ix0 * xsw) * (int)sizeof(T);
-      t.yo = pv ? n * a.ysn + oy * a.ysh + ox * a.ysw : -1;
-      uint32_t rm = 0, cm = 0, mask = 0;
-      for (int d = 0; d < a.KS; ++d) {
-        rm |= (uint32_t)((unsigned)(t.iy0 + d) < (unsigned)a.H) << d;
-        cm |= (uint32_t)((unsigned)(t.ix0 + d) < (unsigned)a.W) << d;
+      const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+      t.xo = n * a.xsn + __mul24(iy0, a.xsh) + __mul24(ix0, a.xsw);
+      t.yo = pv ? n * a.ysn + __mul24(oy, a.ysh) + __mul24(ox, a.ysw) : MGDT_OOB;
+      t.x2o = t.r1o = t.r2o = 0;
+      if (EXTRA && a.x2) t.x2o = n * a.x2sn + __mul24(iy0, a.x2sh) + __mul24(ix0, a.x2sw);
+      if (a.r1) t.r1o = pv ? n * a.r1sn + __mul24(oy, a.r1sh) + __mul24(ox, a.r1sw) : MGDT_OOB;
+      if (a.r2) t.r2o = pv ? n * a.r2sn + __mul24(oy, a.r2sh) + __mul24(ox, a.r2sw) : MGDT_OOB;
+      uint32_t mask = 1u;
+      if (a.KS == 3) {
+        const uint32_t rm = (uint32_t)((unsigned)iy0 < (unsigned)a.H) | ((uint32_t)((unsigned)(iy0 + 1) < (unsigned)a.H) << 1) |
+                            ((uint32_t)((unsigned)(iy0 + 2) < (unsigned)a.H) << 2);
+        const uint32_t cm = (uint32_t)((unsigned)ix0 < (unsigned)a.W) | ((uint32_t)((unsigned)(ix0 + 1) < (unsigned)a.W) << 1) |
+                            ((uint32_t)((unsigned)(ix0 + 2) < (unsigned)a.W) << 2);
+        mask = ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u);
       }
-      for (int d = 0; d < a.KS; ++d)
-        if ((rm >> d) & 1u) mask |= cm << (d * a.KS);
       t.vm = pv ? mask : 0u;   // bit t set <=> tap t of this pixel lies inside the image (0 for rows past M)
       S[mt] = t;
     }
@@ -149,32 +193,35 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
 
   // activation fragments of one K-chunk (table entry e): each lane fetches the 16 bytes it feeds to the MFMA.  Padding taps /
   // tail rows / padded chunks get an out-of-range offset and the hardware returns zeros: no branch, no select.
-  auto load_chunk = [&](const uint2 e, const TileState(&S)[MT], frag(&P)[MT]) __attribute__((always_inline)) {
+  auto load_chunk = [&](const uint4* ep, const TileState(&S)[MT], frag(&P)[MT]) __attribute__((always_inline)) {
+    uint32_t ex, ey, ez = 0, ew = 0;
+    if (EXTRA) { const uint4 e = *ep; ex = e.x; ey = e.y; ez = e.z; ew = e.w; }
+    else { const uint2 e = *(const uint2*)ep; ex = e.x; ey = e.y; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bool ok = (S[mt].vm >> e.y) & 1u;
-      const uint32_t off = ok ? (uint32_t)S[mt].xo + e.x : 0xFFFFFFF0u;
+      const bool ok = (S[mt].vm >> ey) & 1u;
+      const uint32_t off = ok ? (uint32_t)S[mt].xo + ex : (uint32_t)MGDT_OOB;
       frag v = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
       if (EXTRA) {
-        const int dy = (int)e.y / a.KS, dx = (int)e.y - dy * a.KS;
-        const int ch = ((int)e.x / (int)sizeof(T) - dy * xsh - dx * xsw);
         if (a.x2) {
-          const uint32_t off2 = ok ? (uint32_t)((S[mt].pn * a.x2sn + (S[mt].iy0 + dy) * a.x2sh + (S[mt].ix0 + dx) * a.x2sw + ch) * (long)sizeof(T)) : 0xFFFFFFF0u;
+          const uint32_t off2 = ok ? (uint32_t)S[mt].x2o + ez : (uint32_t)MGDT_OOB;
           v = frag_add<T>(v, __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(x2rs, off2, 0, 0)));
         }
         if (ok && (a.in_scale || a.in_shift))
-          v = frag_affine<T>(v, a.in_scale ? a.in_scale + (long)S[mt].pn * a.Cin + ch : nullptr, a.in_shift ? a.in_shift + ch : nullptr);
+          v = frag_affine<T>(v, a.in_scale ? a.in_scale + (long)S[mt].pn * a.Cin + ew : nullptr, a.in_shift ? a.in_shift + ew : nullptr);
       }
       P[mt] = v;
     }
   };
 
   f32x4 acc[NT][MT];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
+  auto init_acc = [&]() __attribute__((always_inline)) {   // accumulators start from the bias of the lane's 4 output channels
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 b = *(const f32x4*)(blds + nt * 16 + 4 * g);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b;
+    }
   };
   auto compute = [&](const char* wp, const frag(&P)[MT]) __attribute__((always_inline)) {   // wp: this lane's slot of the chunk's weight blocks
 #pragma unroll
@@ -184,28 +231,22 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma(Wf, P[mt], acc[nt][mt]);
     }
   };
-  // lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r); the activation switch is hoisted out of the loops
+  // lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r); stores / residual loads go through bounds-checked descriptors, so
+  // tail pixels and padded output channels need no branch.  The activation switch is hoisted out of the loops.
+  const bool ragged = (nb0 + NT) * 16 > a.Cout;   // this workgroup's last cout block is partly padding
   auto epilogue_act = [&](const TileState(&S)[MT], auto actf) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if (S[mt].yo < 0) continue;
-      long r1o = 0, r2o = 0;
-      if (a.r1 || a.r2) {
-        int oy = (S[mt].iy0 + a.pad) / a.stride, ox = (S[mt].ix0 + a.pad) / a.stride;
-        r1o = S[mt].pn * a.r1sn + oy * a.r1sh + ox * a.r1sw;
-        r2o = S[mt].pn * a.r2sn + oy * a.r2sh + ox * a.r2sw;
-      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int co = (nb0 + nt) * 16 + 4 * g;
-        if (co >= a.Cout) continue;
-        const f32x4 b = *(const f32x4*)(blds + nt * 16 + 4 * g);
+        const int cob = ((nb0 + nt) * 16 + 4 * g) * SZ;
+        const int dead = (ragged && cob >= a.Cout * SZ) ? MGDT_OOB : 0;
         f32x4 v = acc[nt][mt];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = actf(v[j] + b[j]);
-        if (a.r1) v += load4<T>((const T*)a.r1 + r1o + co);
-        if (a.r2) v += load4<T>((const T*)a.r2 + r2o + co);
-        store4<T>((T*)a.y + S[mt].yo + co, v);
+        for (int j = 0; j < 4; ++j) v[j] = actf(v[j]);
+        if (a.r1) v += bload4<T>(r1rs, (uint32_t)(S[mt].r1o | dead) + cob);
+        if (a.r2) v += bload4<T>(r2rs, (uint32_t)(S[mt].r2o | dead) + cob);
+        bstore4<T>(yrs, (uint32_t)(S[mt].yo | dead) + cob, v);
       }
     }
   };
@@ -223,23 +264,23 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   int tile = blockIdx.x;
   setup(tile, cur);
   frag P[D][MT];
-  const uint2* tab_g = ptab + g;                 // this lane's column of the piece table
-  load_chunk(tab_g[0], cur, P[0]);               // first loads in flight BEFORE the weight panel is staged
-  if constexpr (L > 1) load_chunk(tab_g[4], cur, P[1]);
-  if constexpr (L > 2) load_chunk(tab_g[8], cur, P[2]);
+  const uint4* tab_g = ptab + g;                 // this lane's column of the piece table
+  load_chunk(tab_g, cur, P[0]);                  // first loads in flight BEFORE the weight panel is staged
+  if constexpr (L > 1) load_chunk(tab_g + 4, cur, P[1]);
+  if constexpr (L > 2) load_chunk(tab_g + 8, cur, P[2]);
   if (!MULTI) { stage(0); __syncthreads(); }
   const char* const wlane = wlds + lane * 16;
   constexpr bool multi = MULTI;   // weight panel staged in K segments (only when even one cout block does not fit in LDS)
 
   for (; tile < 8 * a.T8; tile += gridDim.x) {
-    zero_acc();
-    const uint2* tp = tab_g + 4 * L;             // table entry of the chunk that step 0 prefetches
+    init_acc();
+    const uint4* tp = tab_g + 4 * L;             // table entry of the chunk that step 0 prefetches
     const char* wp = wlane;                      // weight blocks of the chunk that step 0 computes
     int kl = 0;                                  // chunk index inside the staged weight segment (multi-segment panels only)
     // one step: prefetch (`ahead` = table entry of a later chunk of THIS tile), then the MFMAs of chunk j
     auto step_cur = [&](int j, auto dtag) __attribute__((always_inline)) {
       constexpr int d = decltype(dtag)::value;
-      load_chunk(*tp, cur, P[(d + L) % D]);
+      load_chunk(tp, cur, P[(d + L) % D]);
       tp += 4;
       if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
       compute(wp, P[d]);
@@ -258,7 +299,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     step_cur(j0, std::integral_constant<int, 0>{});
     auto step_last = [&](int j, auto dtag) __attribute__((always_inline)) {
       constexpr int d = decltype(dtag)::value;
-      load_chunk(tab_g[4 * (d - 1)], nxt, P[(d + L) % D]);
+      load_chunk(tab_g + 4 * (d - 1), nxt, P[(d + L) % D]);
       if (j < a.nchunks) {
         if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
         compute(wp, P[d]);
