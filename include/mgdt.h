@@ -58,6 +58,17 @@ int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_sca
                     const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
                     const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- ConvNeXtV2 block MLP, hidden map kept on chip (nn/modules/convnextv2.py:62-77: pwconv1 -> GELU -> GRN -> pwconv2 -> + input).
+ * t = LayerNorm output, res = the block input, y = res + pwconv2(GRN(gelu(pwconv1(t)))).  Two launches: GRN statistics, then
+ * apply (both compute pwconv1 + GELU).  w1 [4c][c], w2 [c][4c] row-major as nn.Linear.weight; gamma/beta [4c] (GRN).
+ * Covered: bf16 with c in {32, 64, 96} (both weight panels in LDS); mgdt_cnx_mlp_packed_bytes returns 0 otherwise and the caller
+ * keeps the mgdt_conv2d_fwd / mgdt_grn_stats_fwd chain. */
+size_t mgdt_cnx_mlp_packed_bytes(int c, int dtype);
+int mgdt_cnx_mlp_pack(const float* w1, const float* b1, const float* w2, const float* b2, int c, void* packed, int dtype, mgdt_stream s);
+size_t mgdt_cnx_mlp_workspace_bytes(int n, int h, int w, int c);
+int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packed, const float* gamma, const float* beta, void* ws,
+                     const mgdt_view* y, int dtype, mgdt_stream s);
+
 /* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
  * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
  * w_gemm: [k*k*cin/groups][cout] fp32 from mgdt_conv_pack_direct; bias fp32[cout].                         */

@@ -40,6 +40,10 @@ PROTOTYPES = {
     'mgdt_nearest_fwd': (_i, [VP, VP, _i, _vp]),
     'mgdt_copy_fwd': (_i, [VP, _i, VP, _i, _vp]),
     'mgdt_dwconv7_ln_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, VP, _i, _vp]),
+    'mgdt_cnx_mlp_packed_bytes': (_sz, [_i, _i]),
+    'mgdt_cnx_mlp_pack': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    'mgdt_cnx_mlp_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'mgdt_cnx_mlp_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, VP, _i, _vp]),
     'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
     'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   const int nb0 = blockIdx.y * NT;
   const int BM = (nthr >> 6) * MT * 16;
   const int nchp = (a.nchunks + D - 1) / D * D;
+  const int ssh = a.stride >> 1;       // stride is 1 or 2 (host-checked): multiply by shifting
 
   for (int p = tid; p < nchp * 4; p += nthr) {   // table padded to nchp chunks: padding pieces carry tap 31 (never valid)
     int tap = p / a.CP, cp = p % a.CP;
@@ -156,28 +157,33 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
       const int m0 = tv ? tile * BM + (wave * MT + mt) * 16 : 0;   // uniform
       const bool pv = tv && m0 + r < a.M;
-      int n, oy, ox;
-      if (a.Wo >= 16) {
-        const int n0 = (int)fdiv((uint32_t)m0, a.fd_howo), rem = m0 - n0 * a.HoWo;
+      int n, oy, ox, n0 = 0;
+      bool bump = false;                                         // fast path: n = n0 (uniform) + bump
+      const bool fast = a.Wo >= 16;
+      if (fast) {
+        n0 = (int)fdiv((uint32_t)m0, a.fd_howo);
+        const int rem = m0 - n0 * a.HoWo;
         const int oy0 = (int)fdiv((uint32_t)rem, a.fd_wo), ox0 = rem - oy0 * a.Wo;
-        n = n0; oy = oy0; ox = ox0 + r;
+        oy = oy0; ox = ox0 + r;
         if (ox >= a.Wo) { ox -= a.Wo; ++oy; }
-        if (oy >= a.Ho) { oy = 0; ++n; }
+        if (oy >= a.Ho) { oy = 0; bump = true; }
+        n = n0 + (bump ? 1 : 0);
       } else {
         const int mm = pv ? m0 + r : 0;
         n = (int)fdiv((uint32_t)mm, a.fd_howo);
         const int rem = mm - n * a.HoWo;
         oy = (int)fdiv((uint32_t)rem, a.fd_wo); ox = rem - oy * a.Wo;
       }
+      auto nmul = [&](int s) __attribute__((always_inline)) { return fast ? n0 * s + (bump ? s : 0) : n * s; };   // n * s without a vector multiply
       TileState t;
       t.pn = n;
-      const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-      t.xo = n * a.xsn + __mul24(iy0, a.xsh) + __mul24(ix0, a.xsw);
-      t.yo = pv ? n * a.ysn + __mul24(oy, a.ysh) + __mul24(ox, a.ysw) : MGDT_OOB;
+      const int iy0 = (oy << ssh) - a.pad, ix0 = (ox << ssh) - a.pad;
+      t.xo = nmul(a.xsn) + __mul24(iy0, a.xsh) + __mul24(ix0, a.xsw);
+      t.yo = pv ? nmul(a.ysn) + __mul24(oy, a.ysh) + __mul24(ox, a.ysw) : MGDT_OOB;
       t.x2o = t.r1o = t.r2o = 0;
-      if (EXTRA && a.x2) t.x2o = n * a.x2sn + __mul24(iy0, a.x2sh) + __mul24(ix0, a.x2sw);
-      if (a.r1) t.r1o = pv ? n * a.r1sn + __mul24(oy, a.r1sh) + __mul24(ox, a.r1sw) : MGDT_OOB;
-      if (a.r2) t.r2o = pv ? n * a.r2sn + __mul24(oy, a.r2sh) + __mul24(ox, a.r2sw) : MGDT_OOB;
+      if (EXTRA && a.x2) t.x2o = nmul(a.x2sn) + __mul24(iy0, a.x2sh) + __mul24(ix0, a.x2sw);
+      if (a.r1) t.r1o = pv ? nmul(a.r1sn) + __mul24(oy, a.r1sh) + __mul24(ox, a.r1sw) : MGDT_OOB;
+      if (a.r2) t.r2o = pv ? nmul(a.r2sn) + __mul24(oy, a.r2sh) + __mul24(ox, a.r2sw) : MGDT_OOB;
       uint32_t mask = 1u;
       if (a.KS == 3) {
         const uint32_t rm = (uint32_t)((unsigned)iy0 < (unsigned)a.H) | ((uint32_t)((unsigned)(iy0 + 1) < (unsigned)a.H) << 1) |

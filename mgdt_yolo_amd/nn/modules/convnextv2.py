@@ -1,4 +1,5 @@
-"""ConvNeXtV2_Block (reference nn/modules/convnextv2.py:48-77) as three fused HIP steps on NHWC:
+"""ConvNeXtV2_Block (reference nn/modules/convnextv2.py:48-77) on NHWC.  bf16 inference with dim in {32, 64, 96}: dw7x7+LN, then
+the whole MLP with the 4C hidden map kept on chip (mgdt_cnx_mlp_fwd).  Otherwise three fused HIP steps:
    1. dw7x7 + bias + LayerNorm(eps 1e-6)                       (mgdt_dwconv7_ln_fwd)
    2. pwconv1 (Linear C->4C) + exact GELU as a 1x1 MFMA conv   (mgdt_conv2d_fwd)
    3. GRN statistics -> per-(image,channel) scale, folded with beta into pwconv2's input affine, + residual
@@ -86,6 +87,10 @@ class ConvNeXtV2_Block(HipModule):
             return self._train_fwd(x, dw, pw1_raw, pw2, gb)
         t = ops.dwconv7_ln(x, dw, self.dwconv.bias.detach().float(), self.norm.weight.detach().float(), self.norm.bias.detach().float(),
                            self.norm.eps)
+        if ops.cnx_mlp_supported(dim, dt):     # hidden 4C map never leaves the chip
+            mlp = self._cached(('mlp', dt), [self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias],
+                               lambda: ops.PackedCnxMlp(self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias, dt))
+            return ops.cnx_mlp(t, x, mlp, gb[0], gb[1])
         t = ops.conv2d(t, pw1, 1, ops.ACT_GELU)
         scale = ops.grn_scale(t, gb[0])
         return ops.conv2d(t, pw2, 1, ops.ACT_NONE, in_scale=scale, in_shift=gb[1], r1=x)

@@ -232,6 +232,38 @@ def grn_scale(t, gamma):
     return sc
 
 
+FUSED_CNX_MLP = True    # tests flip this to compare against the three-launch chain
+
+
+def cnx_mlp_supported(c, dtype):
+    """True when the fused ConvNeXtV2 MLP kernels cover (c, dtype); otherwise callers keep the conv/GRN chain."""
+    return FUSED_CNX_MLP and L.lib().mgdt_cnx_mlp_packed_bytes(int(c), dtype_code(dtype)) > 0
+
+
+class PackedCnxMlp:
+    """pwconv1/pwconv2 weights + biases in the fragment order of the fused MLP kernels (see mgdt_cnx_mlp_pack)."""
+
+    def __init__(self, w1, b1, w2, b2, dtype):
+        c = w2.shape[0]
+        dev = w1.device
+        self.c, self.dtype = c, dtype
+        self.blob = torch.empty(L.lib().mgdt_cnx_mlp_packed_bytes(c, dtype_code(dtype)), dtype=torch.uint8, device=dev)
+        f = lambda t: t.detach().float().contiguous()
+        w1, b1, w2, b2 = f(w1), f(b1), f(w2), f(b2)
+        L.check(L.lib().mgdt_cnx_mlp_pack(ptr(w1), ptr(b1), ptr(w2), ptr(b2), c, ptr(self.blob), dtype_code(dtype), stream()))
+
+
+def cnx_mlp(t, res, pk, gamma, beta, out=None):
+    """out = res + pwconv2(GRN(gelu(pwconv1(t)))) with the hidden map kept on chip (mgdt_cnx_mlp_fwd)."""
+    b, c, h, w = t.shape
+    out = like(t) if out is None else out
+    ws = torch.empty(L.lib().mgdt_cnx_mlp_workspace_bytes(b, h, w, c), dtype=torch.uint8, device=t.device)
+    if _PROF is not None:
+        _META['cnx_mlp_fwd'] = dict(shape=(b, c, h, w, c, 1, 1), flops=2.0 * b * h * w * c * 4 * c * 3, bytes=float(4 * b * h * w * c * t.element_size()))
+    _launch('cnx_mlp_fwd', 'mgdt_cnx_mlp_fwd', vp(t), vp(res), ptr(pk.blob), ptr(gamma), ptr(beta), ptr(ws), vp(out), dtype_code(t.dtype), stream())
+    return out
+
+
 def inject(local, ga, gf, out=None):
     out = like(local) if out is None else out
     _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())

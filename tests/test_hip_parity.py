@@ -72,6 +72,32 @@ def test_module_bf16_close_to_reference(golden, name):
     assert err < 3e-2, err
 
 
+@pytest.mark.parametrize('dim,hw', [(96, (40, 40)), (64, (13, 9)), (32, (7, 21))])
+def test_convnext_fused_mlp_matches_three_launch_chain(dim, hw):
+    """bf16: the on-chip MLP (mgdt_cnx_mlp_fwd, hidden map recomputed, never stored) vs conv -> GRN stats -> conv.
+    Both round the hidden map to bf16 at the same point; what differs is the fp32 summation order of the GRN statistic and
+    of pwconv2's K loop, so the outputs agree to bf16 resolution (stated: 2e-2 of the output's max magnitude)."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import ConvNeXtV2_Block
+    m = seed_state_dict_(ConvNeXtV2_Block(dim), 3).eval().to(DEV)
+    with torch.no_grad():
+        m.grn.gamma.normal_(0, 0.5)
+        m.grn.beta.normal_(0, 0.5)
+    x = torch.randn(3, dim, *hw, generator=torch.Generator().manual_seed(5)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.cnx_mlp_supported(dim, torch.bfloat16)
+    with torch.no_grad():
+        y_fused = m(x).float()
+        ops.FUSED_CNX_MLP = False
+        try:
+            y_chain = m(x).float()
+        finally:
+            ops.FUSED_CNX_MLP = True
+        y32 = m(x.float()).float()      # fp32 path (always the chain) as the yardstick
+    scale = y32.abs().max().item()
+    assert (y_fused - y_chain).abs().max().item() < 2e-2 * scale
+    assert (y_fused - y32).abs().max().item() < 3e-2 * scale
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
