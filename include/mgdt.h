@@ -69,6 +69,16 @@ size_t mgdt_cnx_mlp_workspace_bytes(int n, int h, int w, int c);
 int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packed, const float* gamma, const float* beta, void* ws,
                      const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- MSPA_C2f hierarchical point-wise front in one launch (nn/modules/block.py:250-259, scale = 4):
+ *   sp0 = act(conv0(x[0:wd])), sp1 = act(conv1(sp0 + x[wd:2wd])), sp2 = act(conv2(sp1 + x[2wd:3wd])), y[i*wd:(i+1)*wd] = sp_i
+ * conv_i = 1x1 conv (wd -> wd) with BN folded.  x, y: N x H x W x 3*wd views (slices of the block input / concat buffer).
+ * Pack the three convs with idx = 0, 1, 2 into one blob.  Covered: bf16, wd % 4 == 0, wd <= 64 (packed_bytes returns 0 otherwise
+ * and the caller keeps three mgdt_conv2d_fwd launches). */
+size_t mgdt_pw_chain_packed_bytes(int wd, int dtype);
+int mgdt_pw_chain_pack(int idx, const float* w_oi, const float* conv_bias, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                       const float* bn_var, float bn_eps, int wd, int dtype, void* packed, mgdt_stream s);
+int mgdt_pw_chain3_fwd(const mgdt_view* x, const void* packed, int wd, int act, const mgdt_view* y, int dtype, mgdt_stream s);
+
 /* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
  * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
  * w_gemm: [k*k*cin/groups][cout] fp32 from mgdt_conv_pack_direct; bias fp32[cout].                         */

@@ -414,3 +414,192 @@ extern "C" int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const 
     default: return mlp_launch<3>(a, gamma, beta, (float*)ws, st);
   }
 }
+
+// ================================================================================================ MSPA point-wise chain
+// MSPA_C2f's hierarchical front (reference nn/modules/block.py:250-259):  sp0 = conv0(x0), sp1 = conv1(sp0 + x1),
+// sp2 = conv2(sp1 + x2) with x_i / sp_i channel slices of width wd of the block input / concat buffer, conv_i = 1x1 conv + BN +
+// SiLU.  Three dependent launches over tiny channel counts become one: each sp_i stays in the MFMA accumulators, is rounded to
+// the storage type (what the next launch would have read back), written to its concat slot and - re-interpreted as a B operand,
+// the K order of the packed weights is permuted to the accumulator order - fed straight to the next GEMM.
+// HBM traffic: 3 wd in + 3 wd out per pixel (the unfused chain reads sp0 / sp1 back: 5 wd in).
+struct ChainArgs {
+  const char* x; int xsn, xsh, xsw; uint32_t x_bytes;
+  char* y; int ysn, ysh, ysw; uint32_t y_bytes;
+  const char* packed;
+  int N, H, W, wd, act, M, HW, tiles;
+  FastDiv fd_hw, fd_w;
+};
+
+constexpr int CHAIN_THREADS = 512;
+
+template <typename T, int NBK, int MT>
+__global__ __launch_bounds__(CHAIN_THREADS) void pw_chain3_kernel(const ChainArgs a) {
+  typedef typename Piece<T>::frag frag;
+  constexpr int PE = Piece<T>::PE, BPC = PE / 4, SZ = (int)sizeof(T);
+  constexpr int KC = (NBK + BPC - 1) / BPC;
+  constexpr int WWORDS = 3 * KC * NBK * 64;                      // 16-byte words of the three weight panels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;
+  float* bl = (float*)(smem + (size_t)WWORDS * 16);               // bias [3][NBK*16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nw = CHAIN_THREADS / 64;
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < WWORDS; i += CHAIN_THREADS) ((uint4*)wl)[i] = ((const uint4*)a.packed)[i];
+  for (int i = tid; i < 3 * NBK * 16; i += CHAIN_THREADS) bl[i] = ((const float*)(a.packed + (size_t)WWORDS * 16))[i];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const char* const wlane = wl + lane * 16;
+  typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int raw2;
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int raw4;
+
+  for (int tile = blockIdx.x * nw + wave; tile < a.tiles; tile += gridDim.x * nw) {
+    int xo[MT], yo[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = (tile * MT + mt) * 16 + r;
+      const bool pv = m < a.M;
+      const int mm = pv ? m : 0;
+      const int n = (int)fdiv((uint32_t)mm, a.fd_hw), rem = mm - n * a.HW;
+      const int oy = (int)fdiv((uint32_t)rem, a.fd_w), ox = rem - oy * a.W;
+      xo[mt] = pv ? n * a.xsn + __mul24(oy, a.xsh) + __mul24(ox, a.xsw) : MGDT_OOB;
+      yo[mt] = pv ? n * a.ysn + __mul24(oy, a.ysh) + __mul24(ox, a.ysw) : MGDT_OOB;
+    }
+    // every input slice of the tile is requested up front (accumulator order: lane (r, g) <- channels blk*16 + 4g .. +3 of pixel r)
+    f32x4 X[3][NBK][MT];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int blk = 0; blk < NBK; ++blk) {
+        const int c = blk * 16 + 4 * g;
+        const int dead = c >= a.wd ? MGDT_OOB : 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) X[i][blk][mt] = bload4<T>(xrs, (uint32_t)(xo[mt] | dead) + (uint32_t)((i * a.wd + c) * SZ));
+      }
+    f32x4 prev[NBK][MT];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      frag Bf[KC][MT];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < PE; ++e) {
+            const int blk = kc * BPC + e / 4;
+            float v = 0.f;
+            if (blk < NBK) v = X[i][blk][mt][e % 4] + (i ? prev[blk][mt][e % 4] : 0.f);
+            Bf[kc][mt][e] = (T)v;
+          }
+#pragma unroll
+      for (int ob = 0; ob < NBK; ++ob) {
+        const f32x4 bias = *(const f32x4*)(bl + (i * NBK + ob) * 16 + 4 * g);
+        const int c = ob * 16 + 4 * g;
+        const int dead = c >= a.wd ? MGDT_OOB : 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 acc = bias;
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) acc = mma(*(const frag*)(wlane + ((i * KC + kc) * NBK + ob) * 1024), Bf[kc][mt], acc);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = (float)(T)(a.act == MGDT_ACT_SILU ? acc[j] * fast_sigmoid(acc[j]) : act_apply(acc[j], a.act));
+          prev[ob][mt] = acc;                                   // already rounded: what the next launch would have read back
+          bstore4<T>(yrs, (uint32_t)(yo[mt] | dead) + (uint32_t)((i * a.wd + c) * SZ), acc);
+        }
+      }
+    }
+  }
+}
+
+// conv `idx` of the chain: BN folded, K in accumulator order, rows = output channels
+template <typename T>
+__global__ void pw_chain_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int wd, int NBK, int KC, int idx, T* __restrict__ out) {
+  constexpr int PE = Piece<T>::PE, BPC = PE / 4;
+  const int total = KC * NBK * 64 * PE;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i % PE; int t = i / PE;
+    const int lane = t % 64; t /= 64;
+    const int ob = t % NBK, kc = t / NBK;
+    const int cin = (kc * BPC + e / 4) * 16 + 4 * (lane >> 4) + e % 4, co = ob * 16 + (lane & 15);
+    float v = 0.f;
+    if (kc * BPC + e / 4 < NBK && cin < wd && co < wd) v = w[(long)co * wd + cin] * (scale ? scale[co] : 1.f);
+    out[(long)idx * total + i] = (T)v;
+  }
+}
+
+__global__ void fold_kernel(const float* cb, const float* g, const float* b, const float* mu, const float* var, float eps, int Cout, int Cpad,
+                            float* scale, float* bias_out);   // conv_igemm.hip
+
+static int chain_nbk(int wd, int dtype) {   // 0: not covered
+  if (dtype != MGDT_BF16 || wd < 4 || wd % 4 || wd > 64) return 0;
+  const int nbk = (wd + 15) / 16;
+  return nbk == 3 ? 4 : nbk;
+}
+static size_t chain_wbytes(int nbk) { return (size_t)3 * ((nbk + 1) / 2) * nbk * 1024; }
+
+extern "C" size_t mgdt_pw_chain_packed_bytes(int wd, int dtype) {
+  const int nbk = chain_nbk(wd, dtype);
+  if (!nbk) return 0;
+  return chain_wbytes(nbk) + (size_t)(3 + 1) * nbk * 16 * sizeof(float);   // weights | bias[3] | BN scale scratch
+}
+
+extern "C" int mgdt_pw_chain_pack(int idx, const float* w, const float* cb, const float* g, const float* b, const float* mu, const float* var, float eps,
+                                  int wd, int dtype, void* packed, mgdt_stream s) {
+  const int nbk = chain_nbk(wd, dtype);
+  if (!nbk || idx < 0 || idx > 2) MGDT_FAIL(MGDT_BAD_SHAPE, "pw_chain_pack: wd=%d dtype=%d idx=%d not covered (bf16, wd %% 4 == 0, wd <= 64)", wd, dtype, idx);
+  if (!w || !packed) MGDT_FAIL(MGDT_BAD_ARG, "pw_chain_pack: null pointer");
+  if ((g != nullptr) != (b != nullptr) || (g != nullptr) != (mu != nullptr) || (g != nullptr) != (var != nullptr))
+    MGDT_FAIL(MGDT_BAD_ARG, "pw_chain_pack: BN arguments must be all present or all NULL");
+  hipStream_t st = (hipStream_t)s;
+  float* bias = (float*)((char*)packed + chain_wbytes(nbk)) + idx * nbk * 16;
+  float* scale = (float*)((char*)packed + chain_wbytes(nbk)) + 3 * nbk * 16;
+  fold_kernel<<<cdiv(nbk * 16, 64), 64, 0, st>>>(cb, g, b, mu, var, eps, wd, nbk * 16, scale, bias);
+  pw_chain_pack_kernel<bf16><<<16, 256, 0, st>>>(w, g ? scale : nullptr, wd, nbk, (nbk + 1) / 2, idx, (bf16*)packed);
+  MGDT_CHECK_LAUNCH("pw_chain_pack");
+  return MGDT_OK;
+}
+
+template <int NBK, int MT>
+static int chain_launch(ChainArgs& a, hipStream_t st) {
+  a.tiles = cdiv(a.M, 16 * MT);
+  const size_t lds = chain_wbytes(NBK) + (size_t)3 * NBK * 16 * sizeof(float);
+  const int grid = std::min(cdiv(a.tiles, CHAIN_THREADS / 64), 2048);
+  pw_chain3_kernel<bf16, NBK, MT><<<grid, CHAIN_THREADS, lds, st>>>(a);
+  MGDT_CHECK_LAUNCH("pw_chain3_fwd");
+  return MGDT_OK;
+}
+
+extern "C" int mgdt_pw_chain3_fwd(const mgdt_view* x, const void* packed, int wd, int act, const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(y) || !packed) MGDT_FAIL(MGDT_BAD_ARG, "pw_chain3: null/empty argument");
+  const int nbk = chain_nbk(wd, dtype);
+  if (!nbk) MGDT_FAIL(MGDT_BAD_SHAPE, "pw_chain3: wd=%d dtype=%d not covered (bf16, wd %% 4 == 0, wd <= 64)", wd, dtype);
+  if (x->c != 3 * wd || y->c != 3 * wd || x->n != y->n || x->h != y->h || x->w != y->w)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "pw_chain3: x and y must be N x H x W x 3*wd views");
+  const long sz = (long)dtype_size(dtype);
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  bool fits = true;
+  auto bind = [&](const mgdt_view* v, const char** p, int* sn, int* sh, int* sw, uint32_t* bytes) {
+    const long ext = ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * sz;
+    if (v->sc != 1 || v->sw % 4 || v->sh % 4 || v->sn % 4 || (uintptr_t)v->p % (4 * sz) || ext >= 0x7fffffffL || v->sh * sz >= (1L << 23) ||
+        v->sw * sz >= (1L << 23)) { fits = false; return; }
+    *p = (const char*)v->p; *sn = (int)(v->sn * sz); *sh = (int)(v->sh * sz); *sw = (int)(v->sw * sz); *bytes = (uint32_t)ext;
+  };
+  const char* yp = nullptr;
+  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes);
+  bind(y, &yp, &a.ysn, &a.ysh, &a.ysw, &a.y_bytes);
+  if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "pw_chain3: views must be 8-byte aligned NHWC (sc == 1), < 2 GiB, row stride < 8 MiB");
+  a.y = (char*)yp;
+  a.packed = (const char*)packed;
+  const long M = (long)x->n * x->h * x->w;
+  if (M > 0x7fffffffL - (1 << 20)) MGDT_FAIL(MGDT_BAD_SHAPE, "pw_chain3: problem too large");
+  a.N = x->n; a.H = x->h; a.W = x->w; a.wd = wd; a.act = act; a.M = (int)M; a.HW = x->h * x->w;
+  a.fd_hw = make_fastdiv((uint32_t)a.HW); a.fd_w = make_fastdiv((uint32_t)x->w);
+  hipStream_t st = (hipStream_t)s;
+  switch (nbk) {
+    case 1: return chain_launch<1, 4>(a, st);
+    case 2: return chain_launch<2, 4>(a, st);
+    default: return chain_launch<4, 2>(a, st);
+  }
+}

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from .conv import Conv, HipModule
+from .conv import Conv, HipModule, act_code
 from .convnextv2 import ConvNeXtV2_Block
 from .spr_module import SPRModule
 
@@ -119,9 +119,12 @@ class MSPA_C2f(HipModule):
         run = (lambda m: m.train_fwd) if train else (lambda m: m.run)
         cat = ops.new_act(b, (s - 1 + n) * wd, h, w, self.convs[0].out_dtype(x), x.device)
         # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
-        run(self.convs[0])(x[:, :wd], out=cat[:, :wd])
-        for i in range(1, s - 1):
-            run(self.convs[i])(cat[:, (i - 1) * wd:i * wd], x2=x[:, i * wd:(i + 1) * wd], out=cat[:, i * wd:(i + 1) * wd])
+        if not train and s == 4 and ops.pw_chain_supported(wd, cat.dtype) and x.dtype == cat.dtype and self._chain_ok():
+            ops.pw_chain3(x[:, :3 * wd], self._packed_chain(cat.dtype), act_code(self.convs[0].act), cat[:, :3 * wd])   # one launch
+        else:
+            run(self.convs[0])(x[:, :wd], out=cat[:, :wd])
+            for i in range(1, s - 1):
+                run(self.convs[i])(cat[:, (i - 1) * wd:i * wd], x2=x[:, i * wd:(i + 1) * wd], out=cat[:, i * wd:(i + 1) * wd])
         # last group: chained bottlenecks, each output kept (block.py:260-263)
         src, pending = cat[:, (s - 2) * wd:(s - 1) * wd], x[:, (s - 1) * wd:s * wd]
         for j, m in enumerate(self.bottleneck):
@@ -136,6 +139,18 @@ class MSPA_C2f(HipModule):
         else:
             attn = at.group_attention(out, s)                      # softmax over the 4 groups, fp32 [B, C]
         return ops.scale_channels(out, attn)
+
+    def _chain_ok(self):
+        """the three front convs are plain 1x1 Conv+BN with one activation (what mgdt_pw_chain3_fwd computes)"""
+        cs = list(self.convs)[:3]
+        return all(hasattr(c, 'bn') and c.conv.kernel_size == (1, 1) and c.conv.groups == 1 and c.conv.in_channels == self.inwidth
+                   and c.conv.out_channels == self.inwidth and act_code(c.act) == act_code(cs[0].act) for c in cs)
+
+    def _packed_chain(self, dtype):
+        cs = list(self.convs)[:3]
+        tens = [t for c in cs for t in (c.conv.weight, c.conv.bias, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var)]
+        return self._cached(('chain', dtype), tens, lambda: ops.PackedPwChain(
+            [(c.conv.weight, c.conv.bias, (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.eps)) for c in cs], dtype))
 
     def backward(self, g):
         out, attn, part, xshape = self._ctx.pop()

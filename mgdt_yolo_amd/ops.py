@@ -232,6 +232,38 @@ def grn_scale(t, gamma):
     return sc
 
 
+FUSED_PW_CHAIN = True   # tests flip this to compare against three conv launches
+
+
+def pw_chain_supported(wd, dtype):
+    return FUSED_PW_CHAIN and L.lib().mgdt_pw_chain_packed_bytes(int(wd), dtype_code(dtype)) > 0
+
+
+class PackedPwChain:
+    """Three wd->wd 1x1 convs (BN folded) in the fragment order of mgdt_pw_chain3_fwd."""
+
+    def __init__(self, convs, dtype):
+        """convs: three (weight (wd, wd, 1, 1), conv_bias or None, bn tuple or None)."""
+        wd = convs[0][0].shape[0]
+        self.wd, self.dtype = wd, dtype
+        self.blob = torch.empty(L.lib().mgdt_pw_chain_packed_bytes(wd, dtype_code(dtype)), dtype=torch.uint8, device=convs[0][0].device)
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        for i, (w, cb, bn) in enumerate(convs):
+            g, b, mu, var, eps = (None, None, None, None, 0.0) if bn is None else bn
+            w, cb, g, b, mu, var = f(w), f(cb), f(g), f(b), f(mu), f(var)
+            L.check(L.lib().mgdt_pw_chain_pack(i, ptr(w), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, wd, dtype_code(dtype), ptr(self.blob), stream()),
+                    'pw_chain_pack')
+
+
+def pw_chain3(x, pk, act, out):
+    """out[:, i*wd:(i+1)*wd] = sp_i of the MSPA point-wise chain (mgdt_pw_chain3_fwd); x, out: (B, 3*wd, H, W) NHWC views."""
+    if _PROF is not None:
+        b, c, h, w = x.shape
+        _META['pw_chain3_fwd'] = dict(shape=(b, pk.wd, h, w, pk.wd, 1, 1), flops=2.0 * b * h * w * pk.wd * pk.wd * 3, bytes=float(2 * b * h * w * c * x.element_size()))
+    _launch('pw_chain3_fwd', 'mgdt_pw_chain3_fwd', vp(x), ptr(pk.blob), pk.wd, act, vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
 FUSED_CNX_MLP = True    # tests flip this to compare against the three-launch chain
 
 

@@ -98,6 +98,30 @@ def test_convnext_fused_mlp_matches_three_launch_chain(dim, hw):
     assert (y_fused - y32).abs().max().item() < 3e-2 * scale
 
 
+@pytest.mark.parametrize('c,n,hw', [(32, 1, (20, 24)), (64, 2, (17, 13)), (128, 2, (9, 11)), (256, 1, (6, 5)), (96, 1, (8, 8)), (192, 1, (5, 7))])
+def test_mspa_pointwise_chain_matches_three_convs(c, n, hw):
+    """bf16: mgdt_pw_chain3_fwd (sp_i kept in accumulators, rounded to bf16 where the unfused chain would store them) vs three
+    mgdt_conv2d_fwd launches.  Same operands, same roundings; only the MFMA K order differs -> agreement to a bf16 ulp or two."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import MSPA_C2f
+    m = seed_state_dict_(MSPA_C2f(c, c, n, True), 7).eval().to(DEV)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+    x = torch.randn(3, c, *hw, generator=torch.Generator().manual_seed(11)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.pw_chain_supported(c // 4, torch.bfloat16)
+    with torch.no_grad():
+        y_fused = m(x).float()
+        ops.FUSED_PW_CHAIN = False
+        try:
+            y_chain = m(x).float()
+        finally:
+            ops.FUSED_PW_CHAIN = True
+    scale = y_chain.abs().max().item()
+    assert scale > 0
+    assert (y_fused - y_chain).abs().max().item() < 1e-2 * scale
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
