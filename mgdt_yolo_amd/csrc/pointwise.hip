@@ -647,6 +647,108 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tiled_kernel(const T* __restri
   }
 }
 
+// Row-sliding variant (C <= 128): a thread owns one channel quad and one ROW of the 8x8 output tile.  Per kernel row it reads the
+// 14 halo values of its row once and reuses each for up to 7 of its 8 outputs from registers: 4x fewer LDS reads and bf16->fp32
+// conversions than one-pixel-per-iteration, 8 independent accumulators of ILP.  LayerNorm: per-pixel partials -> 64 threads
+// reduce over the quads -> broadcast, twice (mean, then centred variance: the two-pass form F.layer_norm uses).
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw,
+                                                             const float* __restrict__ dw, const float* __restrict__ db,
+                                                             const float* __restrict__ lw, const float* __restrict__ lb, float eps,
+                                                             T* __restrict__ y, long ysn, long ysh, long ysw, int H, int W, int C,
+                                                             T* __restrict__ uo, long usn, long ush, long usw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+  const int Q = C / 4;                                  // blockDim.x == 8 * Q
+  constexpr int HH = DW_TH + 6, HW_ = DW_TW + 6, NPIX = DW_TH * DW_TW;
+  T* halo = (T*)smem_dw;                                // [HH][HW_][C]
+  float* wl = (float*)(smem_dw + (((size_t)HH * HW_ * C * sizeof(T) + 15) & ~(size_t)15));   // [49][C]
+  float* red = wl + 49 * C;                             // [NPIX][Q] partial sums (reused for mean and variance)
+  float* stat = red + NPIX * Q;                         // [NPIX] mean, then rstd
+  const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
+  const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
+  const int ty0 = (tr / tiles_x) * DW_TH, tx0 = (tr % tiles_x) * DW_TW;
+  const int q = threadIdx.x % Q, row = threadIdx.x / Q;
+  // stage the halo (zero padding outside the image); q, row fixed per thread.  Loads are issued in batches of 5 before their LDS
+  // stores so that a thread has 5 global requests in flight instead of one (25 dependent round trips otherwise).
+  constexpr int NST = (HH * HW_ + DW_TH - 1) / DW_TH, BATCH = 5;
+  static_assert(NST % BATCH == 0, "halo staging batches");
+#pragma unroll 1
+  for (int b0 = 0; b0 < NST; b0 += BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int p = row + (b0 + i) * DW_TH;
+      const int hy = p / HW_, hx = p % HW_;
+      const int iy = ty0 + hy - 3, ix = tx0 + hx - 3;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p < HH * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[i] = load4<T>(x + n * xsn + iy * xsh + ix * xsw + q * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int p = row + (b0 + i) * DW_TH;
+      if (p < HH * HW_) store4<T>(halo + (long)p * C + q * 4, v[i]);
+    }
+  }
+  for (int i = threadIdx.x; i < 49 * Q; i += blockDim.x) *(f32x4*)(wl + i * 4) = *(const f32x4*)(dw + i * 4);
+  __syncthreads();
+  f32x4 acc[DW_TW];
+  {
+    const f32x4 bq = *(const f32x4*)(db + q * 4);
+#pragma unroll
+    for (int k = 0; k < DW_TW; ++k) acc[k] = bq;
+  }
+#pragma unroll 1
+  for (int ky = 0; ky < 7; ++ky) {
+    const T* hrow = halo + (long)(row + ky) * HW_ * C + q * 4;
+    f32x4 in[HW_];
+#pragma unroll
+    for (int i = 0; i < HW_; ++i) in[i] = load4<T>(hrow + i * C);
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const f32x4 wv = *(const f32x4*)(wl + (ky * 7 + kx) * C + q * 4);
+#pragma unroll
+      for (int k = 0; k < DW_TW; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(in[k + kx][j], wv[j], acc[k][j]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DW_TW; ++k) red[(row * DW_TW + k) * Q + q] = acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  __syncthreads();
+  if (threadIdx.x < NPIX) {
+    float m = 0.f;
+    for (int j = 0; j < Q; ++j) m += red[threadIdx.x * Q + j];
+    stat[threadIdx.x] = m / (float)C;
+  }
+  __syncthreads();
+  float mean[DW_TW];
+#pragma unroll
+  for (int k = 0; k < DW_TW; ++k) {
+    mean[k] = stat[row * DW_TW + k];
+    const f32x4 d = acc[k] - mean[k];
+    red[(row * DW_TW + k) * Q + q] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  }
+  __syncthreads();
+  if (threadIdx.x < NPIX) {
+    float var = 0.f;
+    for (int j = 0; j < Q; ++j) var += red[threadIdx.x * Q + j];
+    stat[threadIdx.x] = 1.f / sqrtf(var / (float)C + eps);
+  }
+  __syncthreads();
+  const f32x4 gq = *(const f32x4*)(lw + q * 4), bq2 = *(const f32x4*)(lb + q * 4);
+  const int oy = ty0 + row;
+  if (oy < H) {
+#pragma unroll
+    for (int k = 0; k < DW_TW; ++k) {
+      const int ox = tx0 + k;
+      if (ox >= W) continue;
+      const float rstd = stat[row * DW_TW + k];
+      if (uo) store4<T>(uo + n * usn + oy * ush + ox * usw + q * 4, acc[k]);
+      store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, (acc[k] - mean[k]) * rstd * gq + bq2);
+    }
+  }
+}
+
 static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, float eps,
                            const mgdt_view* y, const mgdt_view* u, int dtype, mgdt_stream s);
 extern "C" int mgdt_dwconv7_ln_fwd(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
@@ -668,6 +770,14 @@ static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* d
     const int Qt = x->c / 4;
     const size_t halo_b = ((size_t)(DW_TH + 6) * (DW_TW + 6) * x->c * dtype_size(dtype) + 15) & ~(size_t)15;
     const size_t lds_t = halo_b + (size_t)49 * x->c * 4 + (size_t)DW_TH * DW_TW * Qt * 4;
+    if (Qt <= 32 && lds_t + 256 <= 64 * 1024) {            // one thread per (channel quad, tile row)
+      const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
+      MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_row_kernel<T><<<x->n * tiles, 8 * Qt, lds_t + DW_TH * DW_TW * sizeof(float), (hipStream_t)s>>>(
+                                     (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c,
+                                     u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0)));
+      MGDT_CHECK_LAUNCH("dwconv7_ln_fwd(row)");
+      return MGDT_OK;
+    }
     if (Qt <= 64 && lds_t <= 64 * 1024) {
       const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
       const int need = cdiv(DW_TH * DW_TW, 256 / Qt);      // pixels per thread
