@@ -79,6 +79,15 @@ int mgdt_pw_chain_pack(int idx, const float* w_oi, const float* conv_bias, const
                        const float* bn_var, float bn_eps, int wd, int dtype, void* packed, mgdt_stream s);
 int mgdt_pw_chain3_fwd(const mgdt_view* x, const void* packed, int wd, int act, const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- InjectionMultiSum_Auto_pool, up-sampling branch, in one launch (nn/modules/block.py:376-399):
+ *   y = local_embedding(x) * bilinear(h_sigmoid(ga)) + bilinear(gf)      (align_corners=False, gate applied before interpolation)
+ * packed_w / bias: the 1x1 local_embedding conv packed by mgdt_conv_pack (BN folded, no activation); ga, gf: equally laid out
+ * N x Hg x Wg x cout maps with Hg <= H, Wg <= W.  mgdt_conv1x1_inject_supported tells whether the shapes are covered (bf16,
+ * cin <= 128, cout in {128, 256}); otherwise the caller runs mgdt_conv2d_fwd + mgdt_inject_fwd. */
+int mgdt_conv1x1_inject_supported(int cin, int cout, int h, int w, int hg, int wg, int dtype);
+int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+                            const mgdt_view* y, int dtype, mgdt_stream s);
+
 /* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
  * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
  * w_gemm: [k*k*cin/groups][cout] fp32 from mgdt_conv_pack_direct; bias fp32[cout].                         */

@@ -1,0 +1,203 @@
+// InjectionMultiSum_Auto_pool (reference nn/modules/block.py:376-399), up-sampling branch, in ONE launch:
+//   y = local_embedding(x) * bilinear(h_sigmoid(ga)) + bilinear(gf)
+// local_embedding is a 1x1 conv + BN (no activation); ga / gf are the global act / embedding maps at (Hg, Wg) <= (H, W).
+// The 256-channel local map never goes to HBM (the unfused pair writes and re-reads it), and every global-map pixel a patch
+// needs is fetched once per workgroup into LDS instead of once per output pixel and tap.
+//
+// Workgroup = 4 waves = a 4 x 16 patch of output pixels; wave w owns output row w (16 pixels = the MFMA N dimension) and all
+// output channels: acc[NB] in the usual D layout (lane (r, g): channels nb*16 + 4g .. +3 of pixel r).  The tail reads the four
+// bilinear taps of the lane's pixel from the LDS patch (8-byte reads at [src pixel][channel]), applies h_sigmoid to the gate
+// taps BEFORE interpolating (block.py:393), and stores 4 consecutive channels.
+#include "conv_igemm_kernel.h"
+
+struct InjArgs {
+  const char* x; int xsn, xsh, xsw; uint32_t x_bytes;
+  const char* ga; const char* gf; int gsn, gsh, gsw;   // equally laid out (host-checked)
+  char* y; int ysn, ysh, ysw; uint32_t y_bytes;
+  const char* wpk; const float* bias;
+  int N, H, W, Cin, Cout, Hg, Wg, PH, PW, tiles_x, tiles_y;
+};
+
+constexpr int INJ_TH = 4, INJ_TW = 16, INJ_THREADS = 256, INJ_CPAD = 8;   // channel stride of an LDS patch pixel: Cout + 8 (bank spread)
+
+// F.interpolate(bilinear, align_corners=False): src = max(0, (dst+0.5)*in/out - 0.5), upper neighbour clamped
+// (no fma contraction: the host sizes the LDS patch with this same function and must get the same integers as the device)
+__device__ __host__ inline void inj_lerp(int o, int isz, int osz, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+  const float scale = (float)isz / (float)osz;
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > isz - 1) i0 = isz - 1;
+  i1 = i0 + (i0 < isz - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+template <typename T, int KC, int NB>
+__global__ __launch_bounds__(INJ_THREADS) void conv1x1_inject_kernel(const InjArgs a) {
+  typedef typename Piece<T>::frag frag;
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int CS = NB * 16 + INJ_CPAD;                 // elements per LDS patch pixel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;                                        // [KC][NB][64][16 B]
+  T* sg = (T*)(smem + (size_t)KC * NB * 1024);            // gate patch  [PH*PW][CS]
+  T* sf = sg + (size_t)a.PH * a.PW * CS;                  // feat patch
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < KC * NB * 64; i += INJ_THREADS) ((uint4*)wl)[i] = ((const uint4*)a.wpk)[i];   // weights once per (persistent) workgroup
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const char* const wlane = wl + lane * 16;
+  const int npatch = a.N * a.tiles_x * a.tiles_y;
+#pragma unroll 1
+  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+  int b = patch;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y, n = b / a.tiles_y;
+  const int oy = ty * INJ_TH + wave, ox = tx * INJ_TW + r;
+  const bool pv = oy < a.H && ox < a.W;
+
+  // activations of my pixel first (they have the longest way to come)
+  const int xo = pv ? n * a.xsn + oy * a.xsh + ox * a.xsw : MGDT_OOB;
+  frag P[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int cb = (kc * 4 + g) * 16;
+    P[kc] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, (cb < a.Cin * SZ) ? (uint32_t)(xo + cb) : (uint32_t)MGDT_OOB, 0, 0));
+  }
+  // source patch of this workgroup: rows/cols touched by its first and last output row/col (uniform)
+  int py0, py1, px0, px1, t0, t1; float tl;
+  inj_lerp(ty * INJ_TH, a.Hg, a.H, py0, t1, tl);
+  inj_lerp(min(ty * INJ_TH + INJ_TH - 1, a.H - 1), a.Hg, a.H, t0, py1, tl);
+  inj_lerp(tx * INJ_TW, a.Wg, a.W, px0, t1, tl);
+  inj_lerp(min(tx * INJ_TW + INJ_TW - 1, a.W - 1), a.Wg, a.W, t0, px1, tl);
+  const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;       // <= PH, PW (host bound)
+  __syncthreads();                                         // the previous patch's tail is done with the LDS maps
+  {
+    constexpr int VPP = NB * 16 / 8;                        // 16-byte vectors per pixel
+    const int nvec = ph * pw * VPP;
+    for (int i = tid; i < nvec; i += INJ_THREADS) {
+      const int v = i % VPP, p = i / VPP;
+      const int sy = p / pw, sx = p - sy * pw;
+      const long go = (long)n * a.gsn + (long)(py0 + sy) * a.gsh + (long)(px0 + sx) * a.gsw + v * 16;
+      const uint4 va = *(const uint4*)(a.ga + go), vf = *(const uint4*)(a.gf + go);
+      *(uint4*)((char*)sg + ((size_t)p * CS + v * 8) * SZ) = va;
+      *(uint4*)((char*)sf + ((size_t)p * CS + v * 8) * SZ) = vf;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = *(const f32x4*)(a.bias + nb * 16 + 4 * g);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = mma(*(const frag*)(wlane + (kc * NB + nb) * 1024), P[kc], acc[nb]);
+
+  // bilinear taps of my pixel inside the patch
+  int y0, y1, x0, x1; float wy1, wx1;
+  inj_lerp(min(oy, a.H - 1), a.Hg, a.H, y0, y1, wy1);
+  inj_lerp(min(ox, a.W - 1), a.Wg, a.W, x0, x1, wx1);
+  const int o00 = ((y0 - py0) * pw + (x0 - px0)) * CS + 4 * g, o01 = ((y0 - py0) * pw + (x1 - px0)) * CS + 4 * g;
+  const int o10 = ((y1 - py0) * pw + (x0 - px0)) * CS + 4 * g, o11 = ((y1 - py0) * pw + (x1 - px0)) * CS + 4 * g;
+  const int yo = pv ? n * a.ysn + oy * a.ysh + ox * a.ysw : MGDT_OOB;
+  auto ld = [&](const T* base, int off) __attribute__((always_inline)) {
+    const bf16x4 v = *(const bf16x4*)(base + off);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  };
+  auto hs = [](f32x4 v) __attribute__((always_inline)) {   // h_sigmoid = relu6(v + 3) / 6 as one fma + clamp (an IEEE divide costs ~10 VALU ops
+    f32x4 o;                                               // per tap; the result differs by <= 1 ulp, far below bf16 resolution)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(fmaf(v[j], 1.f / 6.f, 0.5f), 0.f), 1.f);
+    return o;
+  };
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int c = nb * 16;
+    // same association as the stand-alone kernel: (v00*lx0 + v01*lx1)*ly0 + (v10*lx0 + v11*lx1)*ly1
+    const f32x4 sig = (hs(ld(sg, o00 + c)) * (1.f - wx1) + hs(ld(sg, o01 + c)) * wx1) * (1.f - wy1) +
+                      (hs(ld(sg, o10 + c)) * (1.f - wx1) + hs(ld(sg, o11 + c)) * wx1) * wy1;
+    const f32x4 feat = (ld(sf, o00 + c) * (1.f - wx1) + ld(sf, o01 + c) * wx1) * (1.f - wy1) +
+                       (ld(sf, o10 + c) * (1.f - wx1) + ld(sf, o11 + c) * wx1) * wy1;
+    // the unfused pair rounds the local map to the storage type before the tail reads it back: keep that rounding
+    f32x4 loc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) loc[j] = (float)(T)acc[nb][j];
+    bstore4<T>(yrs, (uint32_t)yo + (uint32_t)((c + 4 * g) * SZ), loc * sig + feat);
+  }
+  }   // patch loop
+}
+
+static int inj_kc(int cin) { return (cin + 31) / 32; }   // K chunks of the packed 1x1 panel (mgdt_conv_pack layout)
+
+// largest source patch any workgroup needs (rows x cols)
+static void inj_patch(int H, int W, int Hg, int Wg, int* PH, int* PW) {
+  int ph = 1, pw = 1, a0, a1, b0, b1; float t;
+  for (int ty = 0; ty * INJ_TH < H; ++ty) {
+    inj_lerp(ty * INJ_TH, Hg, H, a0, a1, t);
+    inj_lerp(std::min(ty * INJ_TH + INJ_TH - 1, H - 1), Hg, H, b0, b1, t);
+    ph = std::max(ph, b1 - a0 + 1);
+  }
+  for (int tx = 0; tx * INJ_TW < W; ++tx) {
+    inj_lerp(tx * INJ_TW, Wg, W, a0, a1, t);
+    inj_lerp(std::min(tx * INJ_TW + INJ_TW - 1, W - 1), Wg, W, b0, b1, t);
+    pw = std::max(pw, b1 - a0 + 1);
+  }
+  *PH = ph; *PW = pw;
+}
+
+static size_t inj_lds(int kc, int nb, int PH, int PW) { return (size_t)kc * nb * 1024 + (size_t)2 * PH * PW * (nb * 16 + INJ_CPAD) * 2; }
+
+/* 1 when mgdt_conv1x1_inject_fwd covers the shapes: bf16, cin <= 128, cout in {128, 256}, up-sampling (h >= hg, w >= wg) */
+extern "C" int mgdt_conv1x1_inject_supported(int cin, int cout, int h, int w, int hg, int wg, int dtype) {
+  if (dtype != MGDT_BF16 || cin % 8 || cin > 128 || (cout != 128 && cout != 256) || h < hg || w < wg || hg < 1 || wg < 1) return 0;
+  int PH, PW;
+  inj_patch(h, w, hg, wg, &PH, &PW);
+  return inj_lds(inj_kc(cin), cout / 16, PH, PW) <= 80 * 1024;   // two workgroups per CU
+}
+
+template <int KC, int NB>
+static int inj_launch(const InjArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_inject_kernel<bf16, KC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv1x1_inject: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  conv1x1_inject_kernel<bf16, KC, NB><<<std::min(a.N * a.tiles_x * a.tiles_y, 512), INJ_THREADS, lds, st>>>(a);   // persistent: 2 per CU
+  MGDT_CHECK_LAUNCH("conv1x1_inject_fwd");
+  return MGDT_OK;
+}
+
+extern "C" int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+                                       const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(ga) || !view_ok(gf) || !view_ok(y) || !packed_w || !bias) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject: null/empty argument");
+  if (!mgdt_conv1x1_inject_supported(x->c, y->c, y->h, y->w, ga->h, ga->w, dtype))
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject: shapes/dtype not covered (see mgdt_conv1x1_inject_supported)");
+  const long sz = 2;
+  if (x->n != y->n || x->h != y->h || x->w != y->w || ga->n != y->n || gf->n != y->n || ga->c != y->c || gf->c != y->c || ga->h != gf->h || ga->w != gf->w ||
+      ga->sn != gf->sn || ga->sh != gf->sh || ga->sw != gf->sw)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject: x/y spatial sizes, ga/gf shapes and layouts must match");
+  auto ok = [&](const mgdt_view* v, int q) { return v->sc == 1 && v->sw % q == 0 && v->sh % q == 0 && v->sn % q == 0 && (uintptr_t)v->p % (q * sz) == 0; };
+  auto ext = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * sz; };
+  if (!ok(x, 8) || !ok(ga, 8) || !ok(gf, 8) || !ok(y, 4) || ext(x) >= 0x7fffffffL || ext(y) >= 0x7fffffffL)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject: views must be aligned NHWC (sc == 1) and < 2 GiB");
+  InjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const char*)x->p; a.xsn = (int)(x->sn * sz); a.xsh = (int)(x->sh * sz); a.xsw = (int)(x->sw * sz); a.x_bytes = (uint32_t)ext(x);
+  a.y = (char*)y->p; a.ysn = (int)(y->sn * sz); a.ysh = (int)(y->sh * sz); a.ysw = (int)(y->sw * sz); a.y_bytes = (uint32_t)ext(y);
+  a.ga = (const char*)ga->p; a.gf = (const char*)gf->p; a.gsn = (int)(ga->sn * sz); a.gsh = (int)(ga->sh * sz); a.gsw = (int)(ga->sw * sz);
+  a.wpk = (const char*)packed_w; a.bias = bias;
+  a.N = y->n; a.H = y->h; a.W = y->w; a.Cin = x->c; a.Cout = y->c; a.Hg = ga->h; a.Wg = ga->w;
+  inj_patch(a.H, a.W, a.Hg, a.Wg, &a.PH, &a.PW);
+  a.tiles_x = cdiv(a.W, INJ_TW); a.tiles_y = cdiv(a.H, INJ_TH);
+  const int kc = inj_kc(a.Cin), nb = a.Cout / 16;
+  const size_t lds = inj_lds(kc, nb, a.PH, a.PW);
+  hipStream_t st = (hipStream_t)s;
+#define INJ_CASE(K, B) if (kc == K && nb == B) return inj_launch<K, B>(a, lds, st);
+  INJ_CASE(1, 8) INJ_CASE(2, 8) INJ_CASE(3, 8) INJ_CASE(4, 8) INJ_CASE(1, 16) INJ_CASE(2, 16) INJ_CASE(3, 16) INJ_CASE(4, 16)
+#undef INJ_CASE
+  MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject: no kernel for kc=%d nb=%d", kc, nb);
+}

@@ -345,9 +345,14 @@ class InjectionMultiSum_Auto_pool(HipModule):
         g = x_g[:, c0:c0 + self.global_inp[self.flag]]      # split(...)[flag] as a channel-slice view
         train = self.training and hasattr(self.local_embedding, 'bn')
         f = (lambda m: m.train_fwd) if train else (lambda m: m.run)
-        local = f(self.local_embedding)(x_l)
         ga = f(self.global_act)(g)
         gf = f(self.global_embedding)(g)
+        le = self.local_embedding
+        dt = le.out_dtype(x_l)
+        if (not train and hasattr(le, 'bn') and act_code(le.act) == ops.ACT_NONE and le.conv.kernel_size == (1, 1) and le.conv.groups == 1
+                and ops.conv1x1_inject_supported(x_l, le.conv.out_channels, ga, dt) and ga.stride() == gf.stride()):
+            return ops.conv1x1_inject(x_l, le.packed(dt, direct=False), ga, gf)   # local map never leaves the chip
+        local = f(le)(x_l)
         if train:
             self.__dict__.setdefault('_ctx', []).append((local, ga, x_g.shape, c0))
         return ops.inject(local, ga, gf)                    # pool vs up-sample branch chosen from the shapes (block.py:369)

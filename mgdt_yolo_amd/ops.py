@@ -296,6 +296,26 @@ def cnx_mlp(t, res, pk, gamma, beta, out=None):
     return out
 
 
+FUSED_INJECT = True     # tests flip this to compare against conv + inject
+
+
+def conv1x1_inject_supported(x, cout, ga, dtype):
+    return bool(FUSED_INJECT and x.dtype == dtype and ga.dtype == dtype and is_nhwc(x) and is_nhwc(ga) and
+                L.lib().mgdt_conv1x1_inject_supported(x.shape[1], cout, x.shape[2], x.shape[3], ga.shape[2], ga.shape[3], dtype_code(dtype)))
+
+
+def conv1x1_inject(x, pk, ga, gf, out=None):
+    """out = conv1x1(x) * bilinear(h_sigmoid(ga)) + bilinear(gf) in one launch (mgdt_conv1x1_inject_fwd)."""
+    b, _, h, w = x.shape
+    if out is None:
+        out = new_act(b, pk.cout, h, w, pk.dtype, x.device)
+    if _PROF is not None:
+        _META['conv1x1_inject_fwd'] = dict(shape=(b, pk.cin, h, w, pk.cout, 1, 1), flops=2.0 * b * h * w * pk.cout * pk.cin,
+                                           bytes=float(b * h * w * (pk.cin + pk.cout) * x.element_size() + 2 * ga.numel() * ga.element_size()))
+    _launch('conv1x1_inject_fwd', 'mgdt_conv1x1_inject_fwd', vp(x), ptr(pk.w), ptr(pk.bias), vp(ga), vp(gf), vp(out), dtype_code(pk.dtype), stream())
+    return out
+
+
 def inject(local, ga, gf, out=None):
     out = like(local) if out is None else out
     _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())

@@ -122,6 +122,32 @@ def test_mspa_pointwise_chain_matches_three_convs(c, n, hw):
     assert (y_fused - y_chain).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('cin,cout,hw,ghw', [(64, 256, (80, 80), (40, 40)), (32, 128, (13, 21), (7, 11)), (96, 256, (9, 9), (9, 9)), (64, 128, (20, 36), (5, 9))])
+def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
+    """bf16: mgdt_conv1x1_inject_fwd (local map kept in accumulators, global maps staged in LDS) vs mgdt_conv2d_fwd + mgdt_inject_fwd.
+    Same roundings and the same interpolation association; only the MFMA K order differs."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import InjectionMultiSum_Auto_pool
+    gc = 2 * cout
+    m = seed_state_dict_(InjectionMultiSum_Auto_pool(cin, cout, global_inp=[gc, gc], flag=0), 9).eval().to(DEV)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+    gen = torch.Generator().manual_seed(13)
+    mk = lambda c, s: (3 * torch.randn(2, c, *s, generator=gen)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x_l, x_g = mk(cin, hw), mk(2 * gc, ghw)
+    with torch.no_grad():
+        y_fused = m([x_l, x_g]).float()
+        ops.FUSED_INJECT = False
+        try:
+            y_pair = m([x_l, x_g]).float()
+        finally:
+            ops.FUSED_INJECT = True
+    scale = y_pair.abs().max().item()
+    assert scale > 0
+    assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
