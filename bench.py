@@ -31,6 +31,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--imgsz', type=int, default=640)
+    ap.add_argument('--input', choices=['model', 'f32', 'u8'], default='model',
+                    help="dtype of the resident image batch: 'model' = the compute dtype, what the reference's predictor hands its model "
+                         "(img.half() / 255, engine/predictor.py:128-129); 'u8' = raw uint8, /255 fused into the stem kernel")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--model', default='mspa_c2f_gd_yolov8')
     ap.add_argument('--scale', default='n')
@@ -90,7 +93,11 @@ def main():
     cfg = get_config(args.model, args.scale, 80)
     tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).eval().to(dev).set_compute_dtype(tdt)
-    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100, rank)).to(dev)     # resident in HBM
+    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100, rank)).to(dev)     # resident in HBM, values in [0, 1]
+    if args.input == 'u8':
+        x = (x * 255).round().clamp_(0, 255).to(torch.uint8)
+    elif args.input == 'model':
+        x = x.to(tdt)
 
     def step():
         y, _ = model(x)
@@ -175,7 +182,7 @@ def main():
                                        f'batch {args.batch}/GPU: forward + decode + NMS(conf 0.25, iou 0.7), hipGraph replay' if graph is not None
                            else f'{args.model}-{args.scale} {args.imgsz}x{args.imgsz} eager',
                            'global_batch': world * args.batch, 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
-                           'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)'},
+                           'input': f'{str(x.dtype).replace("torch.", "")} NCHW images resident in HBM', 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)'},
                 'roofline': roof}
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(cfg, model, args)

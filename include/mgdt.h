@@ -24,7 +24,7 @@ typedef void* mgdt_stream; /* hipStream_t */
 
 typedef enum { MGDT_OK = 0, MGDT_BAD_SHAPE = -1, MGDT_BAD_DTYPE = -2, MGDT_LAUNCH_FAIL = -3, MGDT_BAD_ARG = -4,
                MGDT_WORKSPACE = -5 } mgdt_status;
-typedef enum { MGDT_F32 = 0, MGDT_BF16 = 1 } mgdt_dtype;
+typedef enum { MGDT_F32 = 0, MGDT_BF16 = 1, MGDT_U8 = 2 /* image input of mgdt_conv2d_direct_fwd only */ } mgdt_dtype;
 typedef enum { MGDT_ACT_NONE = 0, MGDT_ACT_SILU = 1, MGDT_ACT_RELU = 2, MGDT_ACT_GELU = 3 } mgdt_act;
 
 /* 4-d activation view; sizes in elements, strides in elements of `dtype`. p may be NULL for "absent". */
@@ -90,6 +90,8 @@ int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const floa
 
 /* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
  * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
+ * Stem (k=3, cin<=4, cout%16==0): x_dtype may also be MGDT_U8 - the uint8 image is divided by 255 on the fly exactly as the
+ * reference's preprocess does (yolo/engine/predictor.py:129, yolo/v8/detect/val.py:34, train.py:64), in fp32.
  * w_gemm: [k*k*cin/groups][cout] fp32 from mgdt_conv_pack_direct; bias fp32[cout].                         */
 int mgdt_conv_pack_direct(const float* w_oihw, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
                           const float* bn_mean, const float* bn_var, float bn_eps, int cin_g, int cout, int k,

@@ -1,6 +1,8 @@
 // Direct (VALU) convolution: the 3-channel stem (reads the caller's NCHW fp32 image in place, writes NHWC),
 // grouped / depthwise convs from the registry (DWConv) and any shape the MFMA kernel does not take.
 // One thread = one output pixel x 16 output channels; weights [K][Cout] fp32 are wave-uniform loads.
+#include <type_traits>
+
 #include "common.h"
 
 __global__ void pack_direct_kernel(const float* __restrict__ w, const float* cb, const float* g, const float* b,
@@ -107,6 +109,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const TX* __restrict__ x
                                                         long ysn, long ysh, long ysw, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                                                         int stride, int act) {
   __shared__ __attribute__((aligned(16))) float wl[9 * 4 * 16 + 16];
+  __shared__ float lut[std::is_same<TX, uint8_t>::value ? 256 : 1];
+  if (std::is_same<TX, uint8_t>::value)   // uint8 image: pixel / 255 with the fp32 division of the reference's preprocess (predictor.py:129,
+    lut[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.f);              // val.py:34, train.py:64), kept in fp32 for the multiply-adds
   const int co0 = blockIdx.y * 16;
   for (int i = threadIdx.x; i < 9 * Cin * 16; i += 256) wl[i] = w[(long)(i / 16) * Cout + co0 + (i % 16)];
   if (threadIdx.x < 16) wl[9 * 4 * 16 + threadIdx.x] = bias[co0 + threadIdx.x];
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const TX* __restrict__ x
       if ((unsigned)ix >= (unsigned)W) continue;
       const TX* xp = x + n * xsn + iy * xsh + ix * xsw;
       for (int ci = 0; ci < Cin; ++ci) {
-        float xv = (float)xp[ci * xsc];
+        float xv;
+        if constexpr (std::is_same<TX, uint8_t>::value) xv = lut[xp[ci * xsc]];
+        else xv = (float)xp[ci * xsc];
         const f32x4* wv = (const f32x4*)(wl + ((ky * 3 + kx) * Cin + ci) * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -162,17 +169,19 @@ extern "C" int mgdt_conv2d_direct_fwd(const mgdt_view* x, int x_dtype, const flo
   long M = (long)x->n * Ho * Wo;
   hipStream_t st0 = (hipStream_t)s;
   if (k == 3 && groups == 1 && x->c <= 4 && y->c % 16 == 0 && y->sc == 1 && y->sw % 4 == 0 && y->sh % 4 == 0 && y->sn % 4 == 0 &&
-      (uintptr_t)y->p % 16 == 0 && x_dtype == MGDT_F32) {   // stem fast path
+      (uintptr_t)y->p % 16 == 0 && (x_dtype == MGDT_F32 || x_dtype == MGDT_U8 || (x_dtype == MGDT_BF16 && dtype == MGDT_BF16))) {   // stem fast path
     dim3 sg(cdiv(M, 256), y->c / 16);
-    if (dtype == MGDT_BF16)
-      conv_stem_kernel<float, bf16><<<sg, 256, 0, st0>>>((const float*)x->p, x->sn, x->sh, x->sw, x->sc, w, bias, (bf16*)y->p, y->sn, y->sh, y->sw, x->n,
-                                                          x->h, x->w, x->c, Ho, Wo, y->c, stride, act);
-    else
-      conv_stem_kernel<float, float><<<sg, 256, 0, st0>>>((const float*)x->p, x->sn, x->sh, x->sw, x->sc, w, bias, (float*)y->p, y->sn, y->sh, y->sw, x->n,
-                                                           x->h, x->w, x->c, Ho, Wo, y->c, stride, act);
+#define STEM(TX, TY) conv_stem_kernel<TX, TY><<<sg, 256, 0, st0>>>((const TX*)x->p, x->sn, x->sh, x->sw, x->sc, w, bias, (TY*)y->p, y->sn, y->sh, y->sw, x->n, \
+                                                              x->h, x->w, x->c, Ho, Wo, y->c, stride, act)
+    if (x_dtype == MGDT_U8) { if (dtype == MGDT_BF16) STEM(uint8_t, bf16); else STEM(uint8_t, float); }
+    else if (x_dtype == MGDT_BF16) STEM(bf16, bf16);
+    else if (dtype == MGDT_BF16) STEM(float, bf16);
+    else STEM(float, float);
+#undef STEM
     MGDT_CHECK_LAUNCH("conv2d_direct_fwd(stem)");
     return MGDT_OK;
   }
+  if (x_dtype == MGDT_U8) MGDT_FAIL(MGDT_BAD_DTYPE, "conv2d_direct: uint8 input is taken by the stem path only (k=3, cin<=4, cout%%16==0)");
   constexpr int COB = 16;
   dim3 grid(cdiv(M, 256), cdiv(y->c, COB));
   hipStream_t st = (hipStream_t)s;

@@ -11,6 +11,7 @@ import torch
 from . import _lib as L
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, BF16, F32, View  # noqa: F401
 
+U8 = 2    # uint8 image input of the stem only (divided by 255 in the kernel)
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
@@ -162,7 +163,7 @@ def conv2d(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=Non
     if pk.direct:
         if x2 is not None or r1 is not None or r2 is not None or in_scale is not None or in_shift is not None:
             raise RuntimeError('direct convolution path has no fused extras')
-        _launch('conv2d_direct_fwd', 'mgdt_conv2d_direct_fwd', vp(x), dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
+        _launch('conv2d_direct_fwd', 'mgdt_conv2d_direct_fwd', vp(x), U8 if x.dtype == torch.uint8 else dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
                                            vp(out), dtype_code(out.dtype), stream())
     else:
         _launch('conv2d_fwd', 'mgdt_conv2d_fwd', vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), pk.k, stride, act,

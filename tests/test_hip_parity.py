@@ -148,6 +148,20 @@ def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
     assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_stem_takes_uint8_images_like_the_reference_preprocess(dtype):
+    """uint8 NCHW image -> stem with /255 fused (predictor.py:129) == float image / 255 fed to the same stem, bit for bit."""
+    from mgdt_yolo_amd.nn.modules import Conv
+    m = seed_state_dict_(Conv(3, 16, 3, 2), 5).eval().to(DEV)
+    m.bn.eps = 1e-3
+    m._cdtype = dtype
+    u8 = torch.randint(0, 256, (2, 3, 37, 45), generator=torch.Generator().manual_seed(2), dtype=torch.uint8).to(DEV)
+    with torch.no_grad():
+        y_u8 = m(u8)
+        y_f = m((u8.cpu().float() / 255).to(DEV))     # CPU true division (ATen's GPU kernel multiplies by 1/255 instead)
+    assert y_u8.dtype == dtype and torch.equal(y_u8, y_f)
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
