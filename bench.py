@@ -31,6 +31,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--imgsz', type=int, default=640)
+    ap.add_argument('--inflight', type=int, default=1, help='batches in flight: S hipGraphs replayed round-robin on S streams (each step is still one full batch)')
     ap.add_argument('--input', choices=['model', 'f32', 'u8'], default='model',
                     help="dtype of the resident image batch: 'model' = the compute dtype, what the reference's predictor hands its model "
                          "(img.half() / 255, engine/predictor.py:128-129); 'u8' = raw uint8, /255 fused into the stem kernel")
@@ -119,6 +120,23 @@ def main():
             with torch.cuda.graph(graph):
                 out = step()
         run = graph.replay if graph is not None else step
+        if graph is not None and args.inflight > 1:
+            # S independent graph instances (own activation / NMS buffers, shared weights) on S streams: step i replays graph i % S, so the
+            # single-workgroup-per-image NMS and the small-map layers of one batch overlap the wide layers of the next
+            graphs, outs, streams = [graph], [out], [torch.cuda.Stream() for _ in range(args.inflight)]
+            for _ in range(args.inflight - 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs.append(step())
+                graphs.append(g)
+            counter = [0]
+
+            def run():
+                i = counter[0] % args.inflight
+                counter[0] += 1
+                streams[i].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(streams[i]):
+                    graphs[i].replay()
 
         for _ in range(args.warmup):
             run()
@@ -137,6 +155,12 @@ def main():
         barrier()
         elapsed = parallel.max_over_ranks(t1 - t0, dev)
         n_det = int(out[2].sum().item())
+        if graph is not None and args.inflight > 1:      # every in-flight instance must have produced the same detections
+            cnt = outs[0][2]
+            valid = torch.arange(outs[0][1].shape[1], device=dev)[None, :] < cnt[:, None]        # rows past counts[b] are never written
+            for o in outs[1:]:
+                assert torch.equal(o[2], cnt) and torch.equal(o[1][valid], outs[0][1][valid]) and torch.equal(o[0][valid], outs[0][0][valid]), \
+                    'in-flight graph instances disagree'
 
         # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
         roof = None
@@ -179,7 +203,7 @@ def main():
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, '
-                                       f'batch {args.batch}/GPU: forward + decode + NMS(conf 0.25, iou 0.7), hipGraph replay' if graph is not None
+                                       f'batch {args.batch}/GPU: forward + decode + NMS(conf 0.25, iou 0.7), hipGraph replay' + (f', {args.inflight} batches in flight' if args.inflight > 1 else '') if graph is not None
                            else f'{args.model}-{args.scale} {args.imgsz}x{args.imgsz} eager',
                            'global_batch': world * args.batch, 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
                            'input': f'{str(x.dtype).replace("torch.", "")} NCHW images resident in HBM', 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)'},
