@@ -65,9 +65,15 @@ class Detect(HipModule):
             xi = x[i]
             b, _, h, w = xi.shape
             feat = ops.new_act(b, self.no, h, w, self.cv2[i][0].out_dtype(xi), xi.device)
-            tb = self.cv2[i][1](self.cv2[i][0](xi))          # Conv.forward: eval -> fused run, train -> batch-stat BN + ctx
+            pk01 = None if self.training else self._merged_first(i, xi, feat.dtype)
+            if pk01 is not None:                              # both branches' first 3x3 conv read xi: one launch, cout = c2 + c3
+                t01 = ops.conv2d(xi, pk01, 1, ops.ACT_SILU)
+                c2 = self.cv2[i][0].conv.out_channels
+                tb, tc = self.cv2[i][1](t01[:, :c2]), self.cv3[i][1](t01[:, c2:])
+            else:
+                tb = self.cv2[i][1](self.cv2[i][0](xi))      # Conv.forward: eval -> fused run, train -> batch-stat BN + ctx
+                tc = self.cv3[i][1](self.cv3[i][0](xi))
             _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
-            tc = self.cv3[i][1](self.cv3[i][0](xi))
             _HeadConv.run(self, self.cv3[i][2], tc, feat[:, r4:])
             if self.training:
                 self.__dict__.setdefault('_ctx', []).append((tb, tc))
@@ -86,6 +92,21 @@ class Detect(HipModule):
             ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
+
+    def _merged_first(self, i, xi, dt):
+        """PackedConv of cat(cv2[i][0], cv3[i][0]) along cout (BN folded per branch), or None when the pair is not two plain
+        3x3 Conv+BN+SiLU layers the MFMA kernel takes."""
+        a, b = self.cv2[i][0], self.cv3[i][0]
+        ok = all(isinstance(m, Conv) and hasattr(m, 'bn') and isinstance(m.act, nn.SiLU) and m.conv.kernel_size == (3, 3) and m.conv.stride == (1, 1)
+                 and m.conv.groups == 1 and m.conv.bias is None for m in (a, b))
+        if not ok or a.bn.eps != b.bn.eps or a.conv.out_channels % 8 or not ops.conv_can_mfma(xi, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels,
+                                                                                            3, 1, 1, dt):
+            return None
+        tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
+        cat = lambda f: torch.cat([f(a).detach().float(), f(b).detach().float()])
+        return self._cached(('first01', i, dt), tens, lambda: ops.PackedConv(
+            cat(lambda m: m.conv.weight), None,
+            (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps), 3, dt))
 
     def backward(self, grads):
         """grads: list of d loss / d raw head maps (one per level, NHWC).  Returns the list of input gradients."""
