@@ -111,6 +111,10 @@ int mgdt_spr_pool_fwd(const mgdt_view* x, float* pooled, int dtype, mgdt_stream 
 int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                       const float* fc2_b, int n, int c, int groups, int h, int w, float* attn, mgdt_stream s);
 int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, const mgdt_view* y, int dtype, mgdt_stream s);
+/* spr_attn + scale_channels in one launch: every workgroup recomputes its image's attention (same order, same bits) and scales
+ * a share of the pixels: y = x * softmax_groups(SPR(pooled)).  `pooled` as written by mgdt_spr_pool_fwd. */
+int mgdt_spr_attn_scale_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+                            const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
 
 /* ---- SPPF pooling: y1,y2,y3 = maxpool5(x), maxpool5(y1), maxpool5(y2) (nn/modules/block.py:138-153) ----- */
 int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const mgdt_view* y2, const mgdt_view* y3, int dtype,

@@ -2,6 +2,8 @@
 // ConvNeXtV2 depthwise+LayerNorm, GRN statistics, the Injection tail and the Detect decode.
 // All work on NHWC views, 4 channels (16 B fp32 / 8 B bf16) per lane, channel-fastest so that a wave touches
 // whole contiguous lines.
+#include <algorithm>
+
 #include "common.h"
 
 #define SPR_SPLITS 16
@@ -227,6 +229,87 @@ extern "C" int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const 
   size_t lds = (size_t)(c * 5 + groups * hid + c) * sizeof(float);
   spr_attn_kernel<<<n, 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, h, w, attn);
   MGDT_CHECK_LAUNCH("spr_attn_fwd");
+  return MGDT_OK;
+}
+
+// attention MLP + channel scaling in one launch: grid (K, N); every workgroup of image n recomputes the (tiny) SPR MLP of that image
+// from the pooled partial sums - identical arithmetic in identical order, so all K copies agree bit for bit - keeps the C softmax
+// weights in LDS and scales its 1/K share of the pixels.  Saves a dependent launch per MSPA block.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
+                                                             const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh,
+                                                             long ysw, FastDiv fd_q, FastDiv fd_w) {
+  extern __shared__ float sm[];
+  const int n = blockIdx.y, cw = C / G, hid = cw / 4;
+  float* pooled = sm;               // [C][5] means
+  float* hbuf = sm + C * 5;         // [G][hid]
+  float* obuf = hbuf + G * hid;     // [C] sigmoid outputs
+  float* att = obuf + C;            // [C] softmax over groups
+  const int hs1 = bin_start(1, H, 2), he0 = bin_end(0, H, 2), ws1 = bin_start(1, W, 2), we0 = bin_end(0, W, 2);
+  const float cnt[5] = {(float)H * W, (float)he0 * we0, (float)he0 * (W - ws1), (float)(H - hs1) * we0, (float)(H - hs1) * (W - ws1)};
+  for (int i = threadIdx.x; i < C * 5; i += 256) {
+    float sum = 0.f;
+    for (int sp = 0; sp < SPR_SPLITS; ++sp) sum += partial[((long)n * SPR_SPLITS + sp) * C * 5 + i];
+    pooled[i] = sum / cnt[i % 5];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < G * hid; o += 256) {   // fc1 + relu (spr_module.py:21-23), as in spr_attn_kernel
+    int gi = o / hid, hj = o % hid;
+    const float* wr = w1 + (long)hj * 5 * cw;
+    float acc = b1[hj];
+    for (int c = 0; c < cw; ++c) acc = fmaf(wr[c], pooled[(gi * cw + c) * 5 + 0], acc);
+    for (int c = 0; c < cw; ++c)
+      for (int bn = 0; bn < 4; ++bn) acc = fmaf(wr[cw + c * 4 + bn], pooled[(gi * cw + c) * 5 + 1 + bn], acc);
+    hbuf[o] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += 256) {
+    int gi = o / cw, c = o % cw;
+    float acc = b2[c];
+    for (int hj = 0; hj < hid; ++hj) acc = fmaf(w2[(long)c * hid + hj], hbuf[gi * hid + hj], acc);
+    obuf[o] = 1.f / (1.f + expf(-acc));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cw; c += 256) {   // softmax over the G groups (block.py:278)
+    float mx = -INFINITY;
+    for (int gi = 0; gi < G; ++gi) mx = fmaxf(mx, obuf[gi * cw + c]);
+    float den = 0.f;
+    for (int gi = 0; gi < G; ++gi) den += expf(obuf[gi * cw + c] - mx);
+    for (int gi = 0; gi < G; ++gi) att[gi * cw + c] = expf(obuf[gi * cw + c] - mx) / den;
+  }
+  __syncthreads();
+  const int Q = C / V, HW = H * W;
+  const int p0 = (int)((long)blockIdx.x * HW / gridDim.x), p1 = (int)((long)(blockIdx.x + 1) * HW / gridDim.x);
+  const uint32_t total = (uint32_t)(p1 - p0) * Q;
+  for (uint32_t i = threadIdx.x; i < total; i += 256) {
+    const int pl = (int)fdiv(i, fd_q), q = (int)i - pl * Q;
+    const int p = p0 + pl, h = (int)fdiv((uint32_t)p, fd_w), w = p - h * W;
+    float v[V];
+    ldv<T, V>(x + n * xsn + h * xsh + w * xsw + q * V, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] *= att[q * V + k];
+    stv<T, V>(y + n * ysn + h * ysh + w * ysw + q * V, v);
+  }
+}
+
+extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+                                       const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (!pooled || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "spr_attn_scale: null/empty argument");
+  const int c = x->c;
+  if (groups < 1 || c % groups || (c / groups) % 4 || c > 4096) MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: c=%d groups=%d", c, groups);
+  if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || y->c != c)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: views must be matching NHWC, c%%4==0");
+  const int cw = c / groups, hid = cw / 4;
+  const size_t lds = (size_t)(c * 5 + groups * hid + 2 * c) * sizeof(float);
+  MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8), {
+    const long vecs = (long)x->h * x->w * (c / V);
+    const int K = (int)std::max<long>(1, std::min<long>(64, vecs / 2048));
+    spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
+                                                                              x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
+                                                                              make_fastdiv((uint32_t)x->w));
+  });
+  MGDT_CHECK_LAUNCH("spr_attn_scale_fwd");
   return MGDT_OK;
 }
 

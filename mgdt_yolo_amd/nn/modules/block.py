@@ -137,7 +137,7 @@ class MSPA_C2f(HipModule):
             attn, part = ops.spr_attention_train(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
             self.__dict__.setdefault('_ctx', []).append((out, attn, part, x.shape))
         else:
-            attn = at.group_attention(out, s)                      # softmax over the 4 groups, fp32 [B, C]
+            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)   # pool, then MLP + scaling in one launch
         return ops.scale_channels(out, attn)
 
     def _chain_ok(self):

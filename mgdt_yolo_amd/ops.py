@@ -184,6 +184,17 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     return attn
 
 
+def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None):
+    """out = x * softmax_over_groups(SPR(x_group)): pooling pass, then attention MLP + scaling in one launch."""
+    b, c, h, w = x.shape
+    part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
+    _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
+    out = like(x) if out is None else out
+    _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
+            dtype_code(x.dtype), stream())
+    return out
+
+
 def scale_channels(x, attn, out=None):
     out = like(x) if out is None else out
     _launch('scale_channels_fwd', 'mgdt_scale_channels_fwd', vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream())
