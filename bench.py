@@ -190,7 +190,15 @@ def main():
             else:
                 ach = meta['bytes'] / avg_s / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-            roof.update({'traffic': None, 'kernel': f'conv_igemm_kernel {name}', 'shape_b_cin_h_w_cout_k_s': list(shape),
+            kern = {'conv2d_fwd': 'conv_igemm_kernel', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
+                    'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel'}.get(name, name)
+            traffic, tsrc = None, None
+            tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected
+            if os.path.exists(tfile):
+                ent = json.load(open(tfile)).get(f'{name}|{args.dtype}|{list(shape)}')
+                if ent:
+                    traffic, tsrc = ent['hbm_bytes_per_launch'], ent.get('source')
+            roof.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': f'{kern} ({name})', 'shape_b_cin_h_w_cout_k_s': list(shape),
                          'avg_us': round(avg_s * 1e6, 2), 'launches_per_step': cnt // 3, 'flops_per_launch': meta['flops'],
                          'bytes_per_launch': meta['bytes'], 'arith_intensity': round(ai, 1),
                          'eager_ms_per_step_by_op': {k: round(v, 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1])},

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   //   resolves its 64 candidates with ballot + shuffles, appends the survivors to the kept list and writes the output rows.
   float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
   unsigned* kidx = (unsigned*)(kb + 5 * a.max_det);                  // sorted position of each kept box
-  __shared__ int s_nkept;
-  if (tid == 0) s_nkept = 0;
+  __shared__ int s_nkept, s_turn;
+  if (tid == 0) { s_nkept = 0; s_turn = 0; }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int md = a.max_det;
@@ -255,35 +255,44 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     bool alive = valid;
     for (int k = 0; k < nk0; ++k)
       if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
-    for (int wv = 0; wv < NMS_THREADS / 64; ++wv) {
-      if (wave == wv) {
-        int nkept = s_nkept;
-        for (int k = nk0; k < nkept; ++k)
+    // phase B, pipelined: the waves take their turn in score order, but while a wave waits for its turn it already tests its
+    // candidates against the boxes the earlier waves publish (kept list + count in LDS), so only the 64-lane resolution itself
+    // is serial.  s_turn = first wave of this round that has not finished; a wave that sees s_turn == its index has, by then,
+    // seen every box kept before it (the count is read after the turn).
+    {
+      int seen = nk0;
+      for (;;) {
+        const int turn = __hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int nk = __hip_atomic_load(&s_nkept, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int k = seen; k < nk; ++k)
           if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
-        u64 mask = __ballot(alive);
-        while (mask && nkept < md) {
-          int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
-          if (lane == i) {
-            kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
-            kidx[nkept] = idx;                    // its output row is written after the scan, in parallel
-            alive = false;
-          }
-          // lane i's LDS write must be ordered before the other lanes' reads: wavefront-scope fence for the compiler, the LDS pipe
-          // itself completes a wave's accesses in order; then a broadcast read replaces five shuffles
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          if (alive && lane > i && suppressed_by(nkept, bx1, by1, bx2, by2, area)) alive = false;
-          ++nkept;
-          mask = __ballot(alive);
-        }
-        if (lane == 0) s_nkept = nkept;
+        seen = nk;
+        if (turn == wave) break;
+        __builtin_amdgcn_s_sleep(2);
       }
-      __syncthreads();
-      const int nk_now = s_nkept;
-      __syncthreads();                // read by all before the next wave's turn may change it -> uniform
-      if (nk_now >= md) break;
+      int nkept = seen;
+      u64 mask = __ballot(alive);
+      while (mask && nkept < md) {
+        int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
+        if (lane == i) {
+          kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
+          kidx[nkept] = idx;                    // its output row is written after the scan, in parallel
+          alive = false;
+        }
+        // lane i's LDS write must be ordered before the other lanes' reads: wavefront-scope fence for the compiler, the LDS pipe
+        // itself completes a wave's accesses in order; then a broadcast read replaces five shuffles
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (alive && lane > i && suppressed_by(nkept, bx1, by1, bx2, by2, area)) alive = false;
+        ++nkept;
+        if (lane == 0) __hip_atomic_store(&s_nkept, nkept, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // later waves may test it now
+        mask = __ballot(alive);
+      }
+      if (lane == 0) __hip_atomic_store(&s_turn, wave + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __syncthreads();
+    if (tid == 0) s_turn = 0;
   }
   // output rows (x1,y1,x2,y2,conf,cls) + anchor index of the kept boxes, one thread per row
   for (int t = tid; t < s_nkept; t += NMS_THREADS) {
