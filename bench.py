@@ -178,29 +178,42 @@ def main():
             per_name = {}
             for (name, _), v in agg.items():
                 per_name[name] = per_name.get(name, 0.0) + v[0] / 3
-            conv = [(k, v) for k, v in agg.items() if v[2] is not None]
-            (name, shape), (ms, cnt, meta) = max(conv, key=lambda kv: kv[1][0])
-            avg_s = ms / cnt * 1e-3
-            ai = meta['flops'] / meta['bytes']
+            # dominant kernel = the kernel (op) with the largest share of the step; `achieved` = its algorithmic bytes (or flops) per launch /
+            # its average launch duration, both averaged over all its launches of one step
+            fam = {}
+            for (name, shape), (ms, cnt, meta) in agg.items():
+                if meta is None:
+                    continue
+                f = fam.setdefault(name, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0, 'shapes': []})
+                f['ms'] += ms; f['n'] += cnt; f['flops'] += meta['flops'] * cnt; f['bytes'] += meta['bytes'] * cnt
+                f['shapes'].append((ms / 3, cnt // 3, list(shape), meta))
+            name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
+            avg_s = f['ms'] / f['n'] * 1e-3
+            flops_l, bytes_l = f['flops'] / f['n'], f['bytes'] / f['n']
+            ai = flops_l / bytes_l
             ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
             if ai >= ridge:
-                ach = meta['flops'] / avg_s / 1e12
+                ach = flops_l / avg_s / 1e12
                 roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                         'frac': round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4)}
             else:
-                ach = meta['bytes'] / avg_s / 1e9
+                ach = bytes_l / avg_s / 1e9
                 roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
             kern = {'conv2d_fwd': 'conv_igemm_kernel', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
                     'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel'}.get(name, name)
             traffic, tsrc = None, None
             tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected
             if os.path.exists(tfile):
-                ent = json.load(open(tfile)).get(f'{name}|{args.dtype}|{list(shape)}')
+                ent = json.load(open(tfile)).get(f'{name}|{args.dtype}|b{args.batch}|{args.imgsz}')
                 if ent:
                     traffic, tsrc = ent['hbm_bytes_per_launch'], ent.get('source')
-            roof.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': f'{kern} ({name})', 'shape_b_cin_h_w_cout_k_s': list(shape),
-                         'avg_us': round(avg_s * 1e6, 2), 'launches_per_step': cnt // 3, 'flops_per_launch': meta['flops'],
-                         'bytes_per_launch': meta['bytes'], 'arith_intensity': round(ai, 1),
+            top = sorted(f['shapes'], key=lambda t: -t[0])[:6]
+            roof.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': f'{kern} ({name})', 'launches_per_step': f['n'] // 3,
+                         'avg_us': round(avg_s * 1e6, 2), 'flops_per_launch': round(flops_l), 'bytes_per_launch': round(bytes_l), 'arith_intensity': round(ai, 1),
+                         'share_of_eager_step': round(f['ms'] / 3 / total_ms, 3),
+                         'largest_shapes_b_cin_h_w_cout_k_s': [{'shape': sh, 'launches': c, 'us_per_launch': round(ms_ / c * 1e3, 1),
+                                                                'GBps': round(m['bytes'] / (ms_ / c * 1e-3) / 1e9), 'TFLOPs': round(m['flops'] / (ms_ / c * 1e-3) / 1e12, 1)}
+                                                               for ms_, c, sh, m in top],
                          'eager_ms_per_step_by_op': {k: round(v, 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1])},
                          'eager_ms_per_step': round(total_ms, 3)})
 
