@@ -88,6 +88,24 @@ int mgdt_conv1x1_inject_supported(int cin, int cout, int h, int w, int hg, int w
 int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
                             const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- TOODHead (nn/modules/head.py:466-572; parity unpinned: mmcv's ModulatedDeformConv2d is not shipped with the reference) --------
+ * GroupNorm + activation (Conv_GN head.py:67-81, DyDCNv2's norm block.py:427-431): y = act(group_norm(x, groups, gamma, beta, eps)). */
+size_t mgdt_groupnorm_workspace_bytes(int n, int c);
+int mgdt_groupnorm_fwd(const mgdt_view* x, const float* gamma, const float* beta, int groups, float eps, int act, void* ws, const mgdt_view* y,
+                       int dtype, mgdt_stream s);
+/* TaskDecomposition layer attention (head.py:107-123): sums[n][c] = sum_hw feat (mgdt_nc_reduce); w1 [hid][c], w2 [stacked][hid];
+ * scale[n][k*feat + j] = sigmoid(w2 relu(w1 avg + b1) + b2)[k] - the per-(image, input channel) scale that turns the reduction
+ * conv into mgdt_conv2d_fwd(in_scale = scale). */
+int mgdt_tood_layer_attn_fwd(const float* sums, int n, int c, int hw, const float* w1, const float* b1, const float* w2, const float* b2, int hid,
+                             int stacked, float* scale, mgdt_stream s);
+/* DCNv2 3x3, stride 1, pad 1, one deform group (block.py:401-432, mmcv modulated_deform_conv): offset_mask = N x H x W x (>=27):
+ * 18 offsets (dy, dx per kernel point) then 9 mask logits (sigmoid applied inside, head.py:525).  w_gemm [9*cin][cout] fp32
+ * (mgdt_conv_pack_direct layout), bias fp32[cout] or NULL. */
+int mgdt_dcnv2_fwd(const mgdt_view* x, const mgdt_view* offset_mask, const float* w_gemm, const float* bias, const mgdt_view* y, int dtype,
+                   mgdt_stream s);
+/* y = x * sigmoid(gate[n,h,w]) (cls_feat * cls_prob, head.py:536); gate: N x H x W x 1 logits. */
+int mgdt_pixel_gate_fwd(const mgdt_view* x, const mgdt_view* gate, const mgdt_view* y, int dtype, mgdt_stream s);
+
 /* ---- direct convolution (any strides/groups/cin; used for the 3-channel stem and odd shapes) ------------
  * Same math as above without the fused extras; x may be fp32 NCHW (x_dtype) while y is `dtype` NHWC.
  * Stem (k=3, cin<=4, cout%16==0): x_dtype may also be MGDT_U8 - the uint8 image is divided by 255 on the fly exactly as the

@@ -50,6 +50,11 @@ PROTOTYPES = {
     'mgdt_conv1x1_inject_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'mgdt_conv1x1_inject_fwd': (_i, [VP, _vp, _vp, VP, VP, VP, _i, _vp]),
     'mgdt_spr_attn_scale_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, VP, VP, _i, _vp]),
+    'mgdt_groupnorm_workspace_bytes': (_sz, [_i, _i]),
+    'mgdt_groupnorm_fwd': (_i, [VP, _vp, _vp, _i, _f, _i, _vp, VP, _i, _vp]),
+    'mgdt_tood_layer_attn_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'mgdt_dcnv2_fwd': (_i, [VP, VP, _vp, _vp, VP, _i, _vp]),
+    'mgdt_pixel_gate_fwd': (_i, [VP, VP, VP, _i, _vp]),
     'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
     'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),

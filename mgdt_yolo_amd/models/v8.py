@@ -38,6 +38,11 @@ def _gd_head():
             [[15], 1, 'Detect', ['nc']]]
 
 
+def _gd_tood_head():
+    """models/v8/mspa_c2f_gd_tood_yolov8.yaml: the GD neck with the task-aligned head, `hidc` = 64 unscaled (works at scale n only)."""
+    return _gd_head()[:-1] + [[[15], 1, 'TOODHead', ['nc', 64]]]
+
+
 def _cfg(block, head, nc):
     return {'nc': nc, 'scales': deepcopy(SCALES), 'backbone': _backbone(block), 'head': head()}
 
@@ -47,12 +52,13 @@ CONFIGS = {
     'mspa_c2f_yolov8': lambda nc=80: _cfg('MSPA_C2f', _pan_head, nc),
     'gd_yolov8': lambda nc=80: _cfg('C2f', _gd_head, nc),
     'mspa_c2f_gd_yolov8': lambda nc=80: _cfg('MSPA_C2f', _gd_head, nc),
+    'mspa_c2f_gd_tood_yolov8': lambda nc=2: _cfg('MSPA_C2f', _gd_tood_head, nc),
 }
 
 
-def get_config(name, scale='n', nc=80):
+def get_config(name, scale='n', nc=None):
     """cfg dict for `name` in CONFIGS at compound-scale letter `scale` (like 'yolov8n.yaml' file stems)."""
-    d = CONFIGS[name](nc)
+    d = CONFIGS[name]() if nc is None else CONFIGS[name](nc)      # nc=None: the YAML file's own class count
     d['scale'] = scale
     d['yaml_file'] = f'{name}.yaml'
     return d

@@ -14,7 +14,7 @@ from ... import ops
 from .block import DFL
 from .conv import Conv, HipModule
 
-__all__ = ('Detect',)
+__all__ = ('Detect', 'TOODHead', 'Conv_GN', 'TaskDecomposition', 'DyDCNv2', 'Scale')
 
 
 class _HeadConv(HipModule):
@@ -125,3 +125,201 @@ class Detect(HipModule):
         for a, b, s in zip(self.cv2, self.cv3, self.stride):
             a[-1].bias.data[:] = 1.0
             b[-1].bias.data[:self.nc] = math.log(5 / self.nc / (640 / s) ** 2)
+
+
+# ====================================================================================================================
+# TOODHead (reference nn/modules/head.py:466-572).  Inference on the HIP kernels; the task-aligned head is not trained here yet.
+# Parity is unpinned: the reference needs mmcv (ModulatedDeformConv2d, ConvModule, Scale), which is not shipped with it and not
+# installed, so no fixture can be generated - the DCNv2 kernel follows mmcv's published modulated_deform_conv kernel and the whole
+# head is checked against `oracle/tood.py` (a restatement, not a reference run).
+# ====================================================================================================================
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: a learnable scalar (constructed by the reference head.py:490, unused by its forward)."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        raise RuntimeError('Scale is a parameter container only: TOODHead.forward never applies it (head.py:537)')
+
+
+class Conv_GN(HipModule):
+    """conv (no bias) + GroupNorm(16) + SiLU (reference head.py:67-81): MFMA conv, then the GroupNorm kernel with the activation."""
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if d != 1 or g != 1 or (p is not None and p != k // 2):
+            raise RuntimeError('Conv_GN: only dense, dilation-1, same-padding convolutions are built')
+        self.conv = nn.Conv2d(c1, c2, k, s, k // 2, groups=g, dilation=d, bias=False)
+        self.gn = nn.GroupNorm(16, c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+
+    def forward(self, x, out=None):
+        from .conv import act_code
+        if self.training:
+            raise NotImplementedError('TOODHead training kernels are not built yet')
+        dt = self.out_dtype(x)
+        k, st = self.conv.kernel_size[0], self.conv.stride[0]
+        mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, st, 1, dt)
+        pk = self._cached(('raw', dt, not mfma), [self.conv.weight], lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma))
+        y = ops.conv2d(x, pk, st, ops.ACT_NONE)
+        return ops.groupnorm(y, self.gn.weight.detach().float(), self.gn.bias.detach().float(), self.gn.num_groups, self.gn.eps, act_code(self.act), out=out)
+
+
+class _ConvModuleBias(nn.Module):
+    """mmcv ConvModule(norm_cfg=None): `conv` with bias + ReLU `activate` - parameter container with the reference's key names."""
+
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, 1, bias=True)
+        self.activate = nn.ReLU(inplace=True)
+
+
+class TaskDecomposition(HipModule):
+    """Layer attention folded into the 1x1 reduction conv (reference head.py:83-131, norm_cfg=None as TOODHead builds it):
+    the per-image weights w[b, k] scale the reduction conv's weight block k == they scale input channel k*feat + j, which is the
+    conv kernel's per-(image, channel) input scale."""
+
+    def __init__(self, feat_channels, stacked_convs, la_down_rate=8, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        if norm_cfg is not None:
+            raise RuntimeError('TaskDecomposition: norm_cfg is None everywhere in the reference head')
+        self.feat_channels, self.stacked_convs = feat_channels, stacked_convs
+        self.in_channels = feat_channels * stacked_convs
+        self.la_conv1 = nn.Conv2d(self.in_channels, self.in_channels // la_down_rate, 1)
+        self.relu = nn.ReLU(inplace=True)
+        self.la_conv2 = nn.Conv2d(self.in_channels // la_down_rate, stacked_convs, 1, padding=0)
+        self.sigmoid = nn.Sigmoid()
+        self.reduction_conv = _ConvModuleBias(self.in_channels, feat_channels)
+
+    def forward(self, feat, avg_feat=None):
+        f32 = lambda t: t.detach().float().reshape(t.shape[0], -1).contiguous()
+        la = self._cached('la', [self.la_conv1.weight, self.la_conv1.bias, self.la_conv2.weight, self.la_conv2.bias],
+                          lambda: (f32(self.la_conv1.weight), self.la_conv1.bias.detach().float().contiguous(), f32(self.la_conv2.weight),
+                                   self.la_conv2.bias.detach().float().contiguous()))
+        scale = ops.tood_layer_attn(feat, la[0], la[1], la[2], la[3], self.stacked_convs)
+        rc = self.reduction_conv.conv
+        dt = self.out_dtype(feat)
+        # as written in the reference the bmm path uses only `.conv.weight`: reduction_conv's bias parameter is never added (head.py:117-127)
+        pk = self._cached(('red', dt), [rc.weight], lambda: ops.PackedConv(rc.weight, None, None, 1, dt))
+        return ops.conv2d(feat, pk, 1, ops.ACT_RELU, in_scale=scale)
+
+
+class _DCNParams(nn.Module):
+    """mmcv ModulatedDeformConv2d(in, out, 3, padding=1, bias=False) as a parameter container (weight (out, in, 3, 3))."""
+
+    def __init__(self, c1, c2, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c2, c1, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(c2)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+
+class DyDCNv2(HipModule):
+    """Modulated deformable conv 3x3 + GroupNorm(16) (reference block.py:401-432)."""
+
+    def __init__(self, in_channels, out_channels, stride=1, norm_cfg=dict(type='GN', num_groups=16, requires_grad=True)):
+        super().__init__()
+        if stride != 1:
+            raise RuntimeError('DyDCNv2: stride 1 only (the head never uses another)')
+        self.with_norm = norm_cfg is not None
+        self.conv = _DCNParams(in_channels, out_channels, bias=not self.with_norm)
+        if self.with_norm:
+            self.norm = nn.GroupNorm(norm_cfg.get('num_groups', 16), out_channels)
+
+    def forward(self, x, offset_mask, act=ops.ACT_NONE):
+        """offset_mask: (B, >=27, H, W) = 18 offsets + 9 mask LOGITS (the sigmoid of head.py:525 runs inside the kernel)."""
+        cw = self.conv.weight
+        wg = self._cached('gemm', [cw], lambda: cw.detach().float().permute(2, 3, 1, 0).reshape(9 * cw.shape[1], cw.shape[0]).contiguous())
+        b = None if self.conv.bias is None else self.conv.bias.detach().float()
+        y = ops.dcnv2(x, offset_mask, wg, b, cw.shape[0])
+        if not self.with_norm:
+            return y
+        return ops.groupnorm(y, self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.num_groups, self.norm.eps, act, out=y)
+
+
+class TOODHead(Detect):
+    """Task-aligned dynamic detection head (reference head.py:466-572): shared Conv_GN stack, task decomposition, DCNv2-aligned box
+    branch, probability-gated class branch; reg_max = 16.  Single shared head over all levels."""
+
+    def __init__(self, nc, hidc, ch=()):
+        HipModule.__init__(self)
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        if any(c != hidc for c in ch):
+            raise RuntimeError(f'TOODHead: every input level must have hidc={hidc} channels, got {list(ch)} (the reference YAML passes hidc unscaled, '
+                               'tasks.py:664-665)')
+        self.share_conv = nn.Sequential(Conv_GN(hidc, hidc // 2, 3), Conv_GN(hidc // 2, hidc // 2, 3))
+        self.cls_decomp = TaskDecomposition(hidc // 2, 2, 16)
+        self.reg_decomp = TaskDecomposition(hidc // 2, 2, 16)
+        self.DyDCNV2 = DyDCNv2(hidc // 2, hidc // 2)
+        self.spatial_conv_offset = nn.Conv2d(hidc, 3 * 3 * 3, 3, padding=1)
+        self.offset_dim = 2 * 3 * 3
+        self.cls_prob_conv1 = nn.Conv2d(hidc, hidc // 4, 1)
+        self.cls_prob_conv2 = nn.Conv2d(hidc // 4, 1, 3, padding=1)
+        self.cv2 = nn.Conv2d(hidc // 2, 4 * self.reg_max, 1)
+        self.cv3 = nn.Conv2d(hidc // 2, self.nc, 1)
+        self.scale = nn.ModuleList(Scale(1.0) for _ in ch)
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+
+    def _bias_conv(self, conv, x, act, dt, pad_to=None):
+        """nn.Conv2d with bias on the conv kernels; `pad_to` appends zero output channels so that cout % 4 == 0 (MFMA path)."""
+        k = conv.kernel_size[0]
+
+        def build():
+            w, b = conv.weight.detach().float(), conv.bias.detach().float()
+            if pad_to and pad_to > w.shape[0]:
+                w = torch.cat([w, w.new_zeros(pad_to - w.shape[0], *w.shape[1:])])
+                b = torch.cat([b, b.new_zeros(pad_to - b.shape[0])])
+            mf = ops.conv_can_mfma(x, w.shape[1], w.shape[0], k, 1, 1, dt)
+            return ops.PackedConv(w, b, None, k, dt, direct=not mf)
+        pk = self._cached((id(conv), dt, pad_to), [conv.weight, conv.bias], build)
+        return ops.conv2d(x, pk, 1, act)
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError('TOODHead training kernels are not built yet (inference only this round)')
+        shape = x[0].shape
+        r4 = 4 * self.reg_max
+        for i in range(self.nl):
+            xi = x[i]
+            b, _, h, w = xi.shape
+            dt = self.share_conv[0].out_dtype(xi)
+            half = self.share_conv[0].conv.out_channels
+            feat = ops.new_act(b, 2 * half, h, w, dt, xi.device)        # torch.cat(stack_res_list) = two channel slots
+            self.share_conv[0](xi, out=feat[:, :half])
+            self.share_conv[1](feat[:, :half], out=feat[:, half:])
+            cls_feat = self.cls_decomp(feat)                            # both decompositions share avg_feat = GAP(feat)
+            reg_feat = self.reg_decomp(feat)
+            om = self._bias_conv(self.spatial_conv_offset, feat, ops.ACT_NONE, dt, pad_to=28)     # 18 offsets | 9 mask logits | pad
+            reg_feat = self.DyDCNV2(reg_feat, om, act=ops.ACT_RELU)      # F.relu(reg_feat) of head.py:537 folded into the GroupNorm pass
+            prob = self._bias_conv(self.cls_prob_conv2, self._bias_conv(self.cls_prob_conv1, feat, ops.ACT_RELU, dt), ops.ACT_NONE, dt)
+            out = ops.new_act(b, self.no, h, w, dt, xi.device)
+            _HeadConv.run(self, self.cv2, reg_feat, out[:, :r4])
+            _HeadConv.run(self, self.cv3, ops.pixel_gate(cls_feat, prob), out[:, r4:])
+            x[i] = out
+        strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])
+        if self.dynamic or self.shape != shape:
+            from ...yolo.utils.tal import make_anchors
+            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, strides, 0.5))
+            self.shape = shape
+        a_total = sum(f.shape[2] * f.shape[3] for f in x)
+        y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
+        a_off = 0
+        for i, f in enumerate(x):
+            ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
+            a_off += f.shape[2] * f.shape[3]
+        return y if self.export else (y, x)
+
+    def backward(self, grads):
+        raise NotImplementedError('TOODHead training kernels are not built yet')
+
+    def bias_init(self):
+        """reference head.py:562-568 (single shared head: the class prior uses stride 16)."""
+        self.cv2.bias.data[:] = 1.0
+        self.cv3.bias.data[:self.nc] = math.log(5 / self.nc / (640 / 16) ** 2)

@@ -18,11 +18,11 @@ import torch.nn as nn
 from .. import ops
 from ..yolo.utils.torch_utils import fuse_conv_and_bn, initialize_weights, intersect_dicts, make_divisible
 from .modules import (C2f, IFM, MSPA_C2f, SPPF, Bottleneck, Concat, Conv, Detect, DWConv, InjectionMultiSum_Auto_pool,
-                      SimFusion_3in, SimFusion_4in, Upsample)
+                      SimFusion_3in, SimFusion_4in, TOODHead, Upsample)
 
 # names a YAML row may use -> class (the reference resolves them with globals()[m] / getattr(torch.nn, ...), tasks.py:630)
 REGISTRY = {c.__name__: c for c in (Conv, DWConv, Concat, Bottleneck, C2f, MSPA_C2f, SPPF, SimFusion_4in, SimFusion_3in, IFM,
-                                    InjectionMultiSum_Auto_pool, Detect)}
+                                    InjectionMultiSum_Auto_pool, Detect, TOODHead)}
 REGISTRY['nn.Upsample'] = Upsample
 
 
@@ -216,7 +216,7 @@ def parse_model(d, ch, verbose=True):
         elif m is Concat:
             c2 = sum(ch[x] for x in f)
             r_out = red[f[0]]
-        elif m is Detect:
+        elif m in (Detect, TOODHead):      # TOODHead's hidc (args[1]) is passed unscaled, as in the reference (tasks.py:660-665)
             args.append([ch[x] for x in f])
             r_out = red[f[0]]
         elif m is SimFusion_4in:

@@ -328,6 +328,38 @@ def conv1x1_inject(x, pk, ga, gf, out=None):
     return out
 
 
+# ------------------------------------------------------------------ TOODHead pieces
+def groupnorm(x, gamma, beta, groups, eps, act, out=None):
+    """out = act(GroupNorm(x)) on NHWC (mgdt_groupnorm_fwd)."""
+    b, c = x.shape[:2]
+    out = like(x) if out is None else out
+    ws = torch.empty(L.lib().mgdt_groupnorm_workspace_bytes(b, c), dtype=torch.uint8, device=x.device)
+    _launch('groupnorm_fwd', 'mgdt_groupnorm_fwd', vp(x), ptr(gamma), ptr(beta), groups, float(eps), act, ptr(ws), vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
+def tood_layer_attn(feat, w1, b1, w2, b2, stacked):
+    """TaskDecomposition's layer attention as a per-(image, input channel) scale fp32 [B, C] for the reduction conv."""
+    b, c, h, w = feat.shape
+    sums = nc_reduce(feat)
+    scale = torch.empty(b, c, dtype=torch.float32, device=feat.device)
+    _launch('tood_layer_attn_fwd', 'mgdt_tood_layer_attn_fwd', ptr(sums), b, c, h * w, ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.shape[0], stacked, ptr(scale), stream())
+    return scale
+
+
+def dcnv2(x, offset_mask, w_gemm, bias, cout):
+    b, _, h, w = x.shape
+    out = new_act(b, cout, h, w, x.dtype, x.device)
+    _launch('dcnv2_fwd', 'mgdt_dcnv2_fwd', vp(x), vp(offset_mask), ptr(w_gemm), ptr(bias), vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
+def pixel_gate(x, gate, out=None):
+    out = like(x) if out is None else out
+    _launch('pixel_gate_fwd', 'mgdt_pixel_gate_fwd', vp(x), vp(gate), vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
 def inject(local, ga, gf, out=None):
     out = like(local) if out is None else out
     _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())

@@ -23,13 +23,13 @@ def seeded_tensor(name, shape, seed=0):
     u = lambda a, b: r.uniform(a, b, shape).astype(np.float32)
     if name.endswith('num_batches_tracked') or name.endswith('dfl.conv.weight'):
         return None
-    if re.search(r'\.(bn|norm)\.weight$', name) or name.endswith('running_var'):
+    if re.search(r'\.(bn|norm|gn)\.weight$', name) or name.endswith('running_var'):
         v = u(0.75, 1.25)
-    elif re.search(r'\.(bn|norm)\.bias$', name) or name.endswith('running_mean'):
+    elif re.search(r'\.(bn|norm|gn)\.bias$', name) or name.endswith('running_mean'):
         v = n(0.0, 0.1)
     elif re.search(r'grn\.(gamma|beta)$', name):
         v = n(0.0, 0.2)
-    elif re.search(r'cv3\.\d+\.2\.bias$', name):      # Detect cls logits bias
+    elif re.search(r'cv3\.\d+\.2\.bias$', name) or re.search(r'\.\d+\.cv3\.bias$', name):      # Detect / TOODHead cls logits bias
         v = n(-3.0, 1.0)
     elif re.search(r'cv2\.\d+\.2\.bias$', name):      # Detect box-distribution bias
         v = n(1.0, 0.5)
@@ -45,7 +45,7 @@ def seeded_tensor(name, shape, seed=0):
         v = n(0.0, gain / np.sqrt(fan_in))
     else:
         v = n(0.0, 0.1)
-    return torch.from_numpy(np.ascontiguousarray(v))
+    return torch.from_numpy(np.ascontiguousarray(v)).reshape(shape)
 
 
 @torch.no_grad()

@@ -262,7 +262,7 @@ def plan_from_yaml(d, ch=3, scale=None):
                 n = 1
         elif m in ('Concat', 'SimFusion_4in'):
             c2 = sum(chs[x] for x in f)
-        elif m == 'Detect':
+        elif m in ('Detect', 'TOODHead'):
             args = [*args, [chs[x] for x in f]]
             c2 = None
         elif m == 'SimFusion_3in':
@@ -329,6 +329,10 @@ def model_forward(d, sd, x, strides, fused=False, scale=None, decode=True, retur
         elif t == 'Detect':
             feats = detect_raw(list(xin), sd, p, fused)
             x = (detect_decode(feats, strides, sd[p + '.dfl.conv.weight'].shape[1], a[0]), feats) if decode else feats
+        elif t == 'TOODHead':
+            from . import tood
+            feats = tood.toodhead_raw(list(xin), sd, p)
+            x = (detect_decode(feats, strides, 16, a[0]), feats) if decode else feats
         ys.append(x if r['i'] in save else None)
         if return_layers:
             layer_out.append(x)

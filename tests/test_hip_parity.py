@@ -162,6 +162,66 @@ def test_stem_takes_uint8_images_like_the_reference_preprocess(dtype):
     assert y_u8.dtype == dtype and torch.equal(y_u8, y_f)
 
 
+# ------------------------------------------------------------------------------------------------ TOODHead (a15, parity unpinned)
+def test_groupnorm_matches_torch_cpu():
+    from mgdt_yolo_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for c, hw in ((32, (20, 24)), (64, (7, 9)), (320, (5, 6))):
+        x = (torch.randn(2, c, *hw, generator=g) * 2 + 0.5)
+        gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+        ref = torch.nn.functional.silu(torch.nn.functional.group_norm(x, 16, gamma, beta, 1e-5))
+        y = ops.groupnorm(x.to(DEV).contiguous(memory_format=torch.channels_last), gamma.to(DEV), beta.to(DEV), 16, 1e-5, ops.ACT_SILU)
+        np.testing.assert_allclose(to_nchw(y), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_dcnv2_matches_oracle_restatement():
+    """mmcv's modulated deformable conv as restated in oracle/tood.py (parity unpinned: mmcv itself is absent)."""
+    from mgdt_yolo_amd import ops
+    from oracle import tood
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 32, 13, 11, generator=g)
+    om = torch.cat([torch.randn(2, 18, 13, 11, generator=g) * 2.5, torch.randn(2, 10, 13, 11, generator=g)], 1)   # offsets reach outside the image
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17
+    ref = tood.modulated_deform_conv3x3(x, om[:, :18], om[:, 18:27].sigmoid(), w)
+    nh = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    y = ops.dcnv2(nh(x), nh(om), w.permute(2, 3, 1, 0).reshape(9 * 32, 32).contiguous().to(DEV), None, 32)
+    np.testing.assert_allclose(to_nchw(y), ref.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_toodhead_matches_oracle_restatement(dtype):
+    """Whole task-aligned head vs oracle/tood.py on seeded weights.  PARITY UNPINNED (no reference run possible: mmcv absent)."""
+    from mgdt_yolo_amd.nn.modules import TOODHead
+    from oracle import tood
+    m = seed_state_dict_(TOODHead(80, 64, (64,)), 21).eval()
+    m.stride = torch.tensor([8.0])
+    sd = {'h.' + k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 64, 20, 24, generator=torch.Generator().manual_seed(8))
+    y_ref, feats_ref = tood.toodhead([x], sd, 'h', [8.0], 80)
+    m = m.to(DEV)
+    with torch.no_grad():
+        y, feats = m([x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)])
+    if dtype == torch.float32:
+        np.testing.assert_allclose(to_nchw(feats[0]), feats_ref[0].numpy(), atol=2e-3, rtol=2e-3)
+        np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), atol=2e-2, rtol=2e-3)     # boxes in pixels (stride 8, reg_max 16)
+    else:
+        err = np.abs(to_nchw(feats[0]) - feats_ref[0].numpy()).max() / np.abs(feats_ref[0].numpy()).max()
+        assert err < 5e-2, err
+
+
+def test_tood_model_e2e_fp32_matches_oracle():
+    from oracle import layers as OL
+    cfg = get_config('mspa_c2f_gd_tood_yolov8', 'n', 80)
+    m = build_model('mspa_c2f_gd_tood_yolov8')
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = seeded_images(1, 160, 160, seed=3)
+    y_ref, feats_ref = OL.model_forward(cfg, sd, x, [8.0])
+    with torch.no_grad():
+        y, feats = m(x.to(DEV))
+    np.testing.assert_allclose(to_nchw(feats[0]), feats_ref[0].numpy(), atol=5e-3, rtol=5e-3)
+    np.testing.assert_allclose(y.cpu().numpy()[:, 4:], y_ref.numpy()[:, 4:], atol=1e-3)
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),

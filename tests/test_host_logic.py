@@ -162,3 +162,35 @@ def test_flat_gradient_all_reduce_gloo_world2():
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(30) for p in ps]
     assert res == [(0, 1.5, 1.5), (1, 1.5, 1.5)]
+
+
+def test_tood_config_builds_and_oracle_dcn_reduces_to_conv():
+    """a15 plumbing on CPU: the TOOD YAML rows parse (hidc passed unscaled like the reference), the state_dict carries the reference's
+    key names, and the oracle's deformable conv with zero offsets / unit mask is the plain 3x3 conv (its only pin: mmcv is absent)."""
+    import torch
+    import torch.nn.functional as F
+    from mgdt_yolo_amd.models import get_config
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from oracle import layers as OL, tood
+    cfg = get_config('mspa_c2f_gd_tood_yolov8', 'n', 80)
+    m = DetectionModel(cfg, verbose=False)
+    head = m.model[-1]
+    assert type(head).__name__ == 'TOODHead' and head.reg_max == 16 and head.no == 80 + 64 and float(m.stride[0]) == 8.0
+    keys = set(m.state_dict())
+    for k in ('share_conv.0.gn.weight', 'cls_decomp.reduction_conv.conv.bias', 'DyDCNV2.conv.weight', 'DyDCNV2.norm.bias', 'spatial_conv_offset.bias',
+              'cls_prob_conv2.weight', 'cv2.bias', 'cv3.weight', 'scale.0.scale', 'dfl.conv.weight'):
+        assert f'model.16.{k}' in keys, k
+    rows, _ = OL.plan_from_yaml(cfg, 3)
+    assert rows[-1]['type'] == 'TOODHead' and rows[-1]['args'] == [80, 64, [64]]
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 8, 7, 9, generator=g), torch.randn(6, 8, 3, 3, generator=g)
+    y = tood.modulated_deform_conv3x3(x, torch.zeros(2, 18, 7, 9), torch.ones(2, 9, 7, 9), w)
+    assert (y - F.conv2d(x, w, None, 1, 1)).abs().max() < 1e-4
+    # an integer shift of every kernel point by (+1, 0) samples the image one row lower, zero outside
+    off = torch.zeros(2, 18, 7, 9)
+    off[:, 0::2] = 1.0
+    y1 = tood.modulated_deform_conv3x3(x, off, torch.ones(2, 9, 7, 9), w)
+    xs = torch.zeros_like(x)
+    xs[:, :, :-1] = x[:, :, 1:]
+    ref = F.conv2d(F.pad(xs, (1, 1, 1, 1)), w)
+    assert (y1[:, :, 1:-1] - ref[:, :, 1:-1]).abs().max() < 1e-4      # interior rows: the borders differ by what each form pads
