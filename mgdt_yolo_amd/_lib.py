@@ -101,7 +101,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                '(mgdt_yolo_amd has no CPU or PyTorch fallback)')
-        l = C.CDLL(LIB_PATH)
+        import torch  # noqa: F401  torch's bundled libamdhip64 must be the HIP runtime of the process: loaded first, our DT_NEEDED
+        l = C.CDLL(LIB_PATH)          # libamdhip64.so.7 resolves to it (a second runtime from /opt/rocm would see no device)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
