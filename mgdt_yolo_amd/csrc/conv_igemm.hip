@@ -161,7 +161,8 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
 
   // tile choice: NT = cout blocks per workgroup - as many as divide NTtot and keep the whole weight panel in LDS
   // (activations are then read NTtot/NT times; once when NT == NTtot), fewer when the grid would starve the 256 CUs
-  const int LDS_PANEL_KIB = 128;
+  int LDS_PANEL_KIB = 128;
+  { const char* e = getenv("MGDT_CONV_PANEL_KIB"); if (e) LDS_PANEL_KIB = atoi(e); }   // experiment knob (not part of the ABI)
   int NT = 1;
   for (int c : {8, 6, 5, 4, 3, 2, 1})
     if (a.NTtot % c == 0 && a.nchunks * c <= LDS_PANEL_KIB) { NT = c; break; }

@@ -3,6 +3,7 @@
 // All work on NHWC views, 4 channels (16 B fp32 / 8 B bf16) per lane, channel-fastest so that a wave touches
 // whole contiguous lines.
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -739,7 +740,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
                                                              const float* __restrict__ dw, const float* __restrict__ db,
                                                              const float* __restrict__ lw, const float* __restrict__ lb, float eps,
                                                              T* __restrict__ y, long ysn, long ysh, long ysw, int H, int W, int C,
-                                                             T* __restrict__ uo, long usn, long ush, long usw) {
+                                                             T* __restrict__ uo, long usn, long ush, long usw, unsigned long long* dbg) {
+  unsigned long long TT[6] = {0, 0, 0, 0, 0, 0};
+  const bool dbgw = dbg && threadIdx.x == 0;
+  if (dbgw) TT[0] = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) char smem_dw[];
   const int Q = C / 4;                                  // blockDim.x == 8 * Q
   constexpr int HH = DW_TH + 6, HW_ = DW_TW + 6, NPIX = DW_TH * DW_TW;
@@ -751,29 +755,40 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
   const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
   const int ty0 = (tr / tiles_x) * DW_TH, tx0 = (tr % tiles_x) * DW_TW;
   const int q = threadIdx.x % Q, row = threadIdx.x / Q;
-  // stage the halo (zero padding outside the image); q, row fixed per thread.  Loads are issued in batches of 5 before their LDS
-  // stores so that a thread has 5 global requests in flight instead of one (25 dependent round trips otherwise).
-  constexpr int NST = (HH * HW_ + DW_TH - 1) / DW_TH, BATCH = 5;
-  static_assert(NST % BATCH == 0, "halo staging batches");
-#pragma unroll 1
-  for (int b0 = 0; b0 < NST; b0 += BATCH) {
-    f32x4 v[BATCH];
+  // stage the halo (zero padding outside the image); q, row fixed per thread.  Loads are issued before their LDS
+  // stores so that a thread has all its 25 global requests in flight at once (one round trip instead of 25 dependent ones: with two
+  // workgroups per CU there is nobody else to hide that latency).
+  constexpr int NST = (HH * HW_ + DW_TH - 1) / DW_TH;
+  {
+    // branch-free: out-of-image pixels get an out-of-range offset of a bounds-checked descriptor (zeros come back), so all NST loads of a
+    // thread are issued back to back
+    const long ext = ((long)(H - 1) * xsh + (long)(W - 1) * xsw + C) * (long)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n * xsn), 0, (int)ext, 0x00020000);
+    f32x4 v[NST];
 #pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      const int p = row + (b0 + i) * DW_TH;
+    for (int i = 0; i < NST; ++i) {
+      const int p = row + i * DW_TH;
       const int hy = p / HW_, hx = p % HW_;
       const int iy = ty0 + hy - 3, ix = tx0 + hx - 3;
-      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p < HH * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[i] = load4<T>(x + n * xsn + iy * xsh + ix * xsw + q * 4);
+      const bool ok = p < HH * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const uint32_t off = ok ? (uint32_t)((iy * xsh + ix * xsw + q * 4) * (long)sizeof(T)) : 0x80000000u;
+      if constexpr (sizeof(T) == 2) {
+        const bf16x4 r4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+        v[i] = f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+      } else {
+        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      }
     }
 #pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      const int p = row + (b0 + i) * DW_TH;
+    for (int i = 0; i < NST; ++i) {
+      const int p = row + i * DW_TH;
       if (p < HH * HW_) store4<T>(halo + (long)p * C + q * 4, v[i]);
     }
   }
+  if (dbgw) TT[1] = wall_clock64();
   for (int i = threadIdx.x; i < 49 * Q; i += blockDim.x) *(f32x4*)(wl + i * 4) = *(const f32x4*)(dw + i * 4);
   __syncthreads();
+  if (dbgw) TT[2] = wall_clock64();
   f32x4 acc[DW_TW];
   {
     const f32x4 bq = *(const f32x4*)(db + q * 4);
@@ -795,6 +810,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
         for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(in[k + kx][j], wv[j], acc[k][j]);
     }
   }
+  if (dbgw) TT[3] = wall_clock64();
 #pragma unroll
   for (int k = 0; k < DW_TW; ++k) red[(row * DW_TW + k) * Q + q] = acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
   __syncthreads();
@@ -818,6 +834,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
     stat[threadIdx.x] = 1.f / sqrtf(var / (float)C + eps);
   }
   __syncthreads();
+  if (dbgw) TT[4] = wall_clock64();
   const f32x4 gq = *(const f32x4*)(lw + q * 4), bq2 = *(const f32x4*)(lb + q * 4);
   const int oy = ty0 + row;
   if (oy < H) {
@@ -830,6 +847,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
       store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, (acc[k] - mean[k]) * rstd * gq + bq2);
     }
   }
+  if (dbgw) { TT[5] = wall_clock64(); for (int i = 0; i < 6; ++i) dbg[blockIdx.x * 6 + i] = TT[i]; }
 }
 
 static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, float eps,
@@ -855,10 +873,22 @@ static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* d
     const size_t lds_t = halo_b + (size_t)49 * x->c * 4 + (size_t)DW_TH * DW_TW * Qt * 4;
     if (Qt <= 32 && lds_t + 256 <= 64 * 1024) {            // one thread per (channel quad, tile row)
       const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
+      static unsigned long long* dbgbuf = nullptr;
+      if (getenv("MGDT_DW_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, (size_t)x->n * tiles * 6 * 8);
       MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_row_kernel<T><<<x->n * tiles, 8 * Qt, lds_t + DW_TH * DW_TW * sizeof(float), (hipStream_t)s>>>(
                                      (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c,
-                                     u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0)));
+                                     u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0, dbgbuf)));
       MGDT_CHECK_LAUNCH("dwconv7_ln_fwd(row)");
+      if (dbgbuf) {
+        const int nwg = x->n * tiles;
+        std::vector<unsigned long long> h((size_t)nwg * 6);
+        (void)hipStreamSynchronize((hipStream_t)s);
+        (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t5 = 0; double ph[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < nwg; ++i) { t0 = std::min(t0, h[i * 6]); t5 = std::max(t5, h[i * 6 + 5]); for (int j = 0; j < 5; ++j) ph[j] += (double)(h[i * 6 + j + 1] - h[i * 6 + j]); }
+        fprintf(stderr, "dwconv row x10ns: span %llu; avg per WG: halo %.0f weights+sync %.0f taps %.0f layernorm %.0f store %.0f\n", t5 - t0, ph[0] / nwg, ph[1] / nwg,
+                ph[2] / nwg, ph[3] / nwg, ph[4] / nwg);
+      }
       return MGDT_OK;
     }
     if (Qt <= 64 && lds_t <= 64 * 1024) {
