@@ -140,17 +140,31 @@ __global__ __launch_bounds__(256) void spr_pool_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int k = 0; k < 5; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (prow < PR) {
-    const long npix = (long)(r1 - r0) * W;
-    for (long p = prow; p < npix; p += PR) {
-      int yy = r0 + (int)(p / W), xx = (int)(p % W);
-      f32x4 v = load4<T>(x + n * sn + yy * sh + xx * sw + q * 4);
-      bool t0 = yy < he0, t1 = yy >= hs1, l0 = xx < we0, l1 = xx >= ws1;
+    // pixels prow, prow + PR, ... of the band in raster order; 4 loads are issued before the (in-order) accumulation so that a thread
+    // keeps 4 requests in flight instead of one, and (yy, xx) advance incrementally instead of by 64-bit divisions
+    const int npix = (r1 - r0) * W;
+    int yy = r0 + prow / W, xx = prow % W;
+    const int dy = PR / W, dx = PR % W;
+    auto advance = [&](int& y_, int& x_) __attribute__((always_inline)) { y_ += dy; x_ += dx; if (x_ >= W) { x_ -= W; ++y_; } };
+    auto accum = [&](f32x4 v, int y_, int x_) __attribute__((always_inline)) {
+      const bool t0 = y_ < he0, t1 = y_ >= hs1, l0 = x_ < we0, l1 = x_ >= ws1;
       acc[0] += v;
       if (t0 && l0) acc[1] += v;
       if (t0 && l1) acc[2] += v;
       if (t1 && l0) acc[3] += v;
       if (t1 && l1) acc[4] += v;
+    };
+    const T* xb = x + n * sn + q * 4;
+    int p = prow;
+    for (; p + 3 * PR < npix; p += 4 * PR) {
+      int ys[4], xs[4];
+      f32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ys[k] = yy; xs[k] = xx; v[k] = load4<T>(xb + yy * sh + xx * sw); advance(yy, xx); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) accum(v[k], ys[k], xs[k]);
     }
+    for (; p < npix; p += PR) { accum(load4<T>(xb + yy * sh + xx * sw), yy, xx); advance(yy, xx); }
   }
   __shared__ float red[256 * 20];
 #pragma unroll
@@ -283,14 +297,32 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   const int Q = C / V, HW = H * W;
   const int p0 = (int)((long)blockIdx.x * HW / gridDim.x), p1 = (int)((long)(blockIdx.x + 1) * HW / gridDim.x);
   const uint32_t total = (uint32_t)(p1 - p0) * Q;
-  for (uint32_t i = threadIdx.x; i < total; i += 256) {
+  auto one = [&](uint32_t i, long& xo, long& yo, int& qv) __attribute__((always_inline)) {
     const int pl = (int)fdiv(i, fd_q), q = (int)i - pl * Q;
     const int p = p0 + pl, h = (int)fdiv((uint32_t)p, fd_w), w = p - h * W;
-    float v[V];
-    ldv<T, V>(x + n * xsn + h * xsh + w * xsw + q * V, v);
+    xo = n * xsn + h * xsh + w * xsw + q * V; yo = n * ysn + h * ysh + w * ysw + q * V; qv = q * V;
+  };
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * 256 < total; i += 4 * 256) {       // 4 independent loads in flight per thread
+    float v[4][V];
+    long yo[4];
+    int qv[4];
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] *= att[q * V + k];
-    stv<T, V>(y + n * ysn + h * ysh + w * ysw + q * V, v);
+    for (int u = 0; u < 4; ++u) { long xo; one(i + u * 256, xo, yo[u], qv[u]); ldv<T, V>(x + xo, v[u]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[u][k] *= att[qv[u] + k];
+      stv<T, V>(y + yo[u], v[u]);
+    }
+  }
+  for (; i < total; i += 256) {
+    long xo, yo; int qv; float v[V];
+    one(i, xo, yo, qv);
+    ldv<T, V>(x + xo, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] *= att[qv + k];
+    stv<T, V>(y + yo, v);
   }
 }
 
