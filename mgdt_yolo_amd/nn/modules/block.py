@@ -339,14 +339,35 @@ class InjectionMultiSum_Auto_pool(HipModule):
         self.global_act = Conv(global_inp[self.flag], oup, 1, act=False)
         self.act = h_sigmoid()
 
+    def _merged_global(self, g):
+        """PackedConv of cat(global_act, global_embedding) along cout, or None when they are not two plain 1x1 Conv+BN(no act) layers."""
+        a, b = self.global_act, self.global_embedding
+        ok = all(hasattr(m, 'bn') and act_code(m.act) == ops.ACT_NONE and m.conv.kernel_size == (1, 1) and m.conv.groups == 1 and m.conv.bias is None
+                 for m in (a, b))
+        dt = a.out_dtype(g)
+        if not ok or a.bn.eps != b.bn.eps or a.conv.out_channels % 8 or not ops.conv_can_mfma(g, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels,
+                                                                                            1, 1, 1, dt):
+            return None
+        tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
+        cat = lambda fn: torch.cat([fn(a).detach().float(), fn(b).detach().float()])
+        return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(
+            cat(lambda m: m.conv.weight), None,
+            (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps), 1, dt))
+
     def forward(self, x):
         x_l, x_g = x
         c0 = sum(self.global_inp[:self.flag])
         g = x_g[:, c0:c0 + self.global_inp[self.flag]]      # split(...)[flag] as a channel-slice view
         train = self.training and hasattr(self.local_embedding, 'bn')
         f = (lambda m: m.train_fwd) if train else (lambda m: m.run)
-        ga = f(self.global_act)(g)
-        gf = f(self.global_embedding)(g)
+        pk2 = None if train else self._merged_global(g)
+        if pk2 is not None:                                 # global_act and global_embedding read the same g: one launch, two channel ranges
+            gaf = ops.conv2d(g, pk2, 1, ops.ACT_NONE)
+            oc = self.global_act.conv.out_channels
+            ga, gf = gaf[:, :oc], gaf[:, oc:]
+        else:
+            ga = f(self.global_act)(g)
+            gf = f(self.global_embedding)(g)
         le = self.local_embedding
         dt = le.out_dtype(x_l)
         if (not train and hasattr(le, 'bn') and act_code(le.act) == ops.ACT_NONE and le.conv.kernel_size == (1, 1) and le.conv.groups == 1
