@@ -43,6 +43,12 @@ def _gd_tood_head():
     return _gd_head()[:-1] + [[[15], 1, 'TOODHead', ['nc', 64]]]
 
 
+def _gd_tood_head_s():
+    """Our own variant for scale s (SURVEY section 8 row a15 / BASELINE configs[3]): the reference YAML's hidc=64 only fits scale n because
+    parse_model leaves it unscaled (tasks.py:664-665 commented out); here hidc = 128 = the s-scale width of the head input."""
+    return _gd_head()[:-1] + [[[15], 1, 'TOODHead', ['nc', 128]]]
+
+
 def _cfg(block, head, nc):
     return {'nc': nc, 'scales': deepcopy(SCALES), 'backbone': _backbone(block), 'head': head()}
 
@@ -52,6 +58,7 @@ CONFIGS = {
     'mspa_c2f_yolov8': lambda nc=80: _cfg('MSPA_C2f', _pan_head, nc),
     'gd_yolov8': lambda nc=80: _cfg('C2f', _gd_head, nc),
     'mspa_c2f_gd_yolov8': lambda nc=80: _cfg('MSPA_C2f', _gd_head, nc),
+    'mspa_c2f_gd_tood_yolov8_hidc128': lambda nc=80: _cfg('MSPA_C2f', _gd_tood_head_s, nc),      # use with scale='s'
     'mspa_c2f_gd_tood_yolov8': lambda nc=2: _cfg('MSPA_C2f', _gd_tood_head, nc),
 }
 

@@ -37,7 +37,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.mgdt_nms_fwd(None, 1, 1, 1, 0.5, 0.5, None, 0, 0, 0, 1, 1, 1.0, None, None, None, None, 0, None) == -4
 
 
-@pytest.mark.parametrize('name', list(CONFIGS))
+@pytest.mark.parametrize('name', [n for n in CONFIGS if not n.endswith('_hidc128')])     # *_hidc128: our own s-scale variant, no reference file
 def test_builtin_graphs_equal_reference_yaml_files(name):
     import yaml
     path = os.path.join(REF_YAML, name + '.yaml')
