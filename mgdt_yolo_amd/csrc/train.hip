@@ -6,7 +6,9 @@
 // normalise with the biased batch variance, update running_var with the unbiased one.
 #include "common.h"
 
-#define RED_SPLITS 32
+#define RED_SPLITS 128
+// channel lanes of a reduction block: the whole channel range when it is narrow, so that all 256 threads have pixels to walk
+static __host__ __device__ inline int red_cw(int c) { return c > 32 ? 64 : c > 16 ? 32 : c > 8 ? 16 : c > 4 ? 8 : 4; }
 
 __device__ __forceinline__ float act_fwd(float u, int act) {
   switch (act) {
@@ -29,29 +31,38 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // partial[split][c][2] (double) = sum over the split's pixels of (f0, f1); pixel ranges are fixed -> deterministic.
 template <typename T, typename F>
 __device__ __forceinline__ void channel_reduce(const mgdt_view v, double* partial, F f) {
-  // grid: (cdiv(C,64), RED_SPLITS); block 256 = 64 channels x 4 pixel lanes
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6, split = blockIdx.y;
+  // grid: (cdiv(C, CW), RED_SPLITS); block 256 = CW channel lanes x 256/CW pixel lanes; four pixels per thread are read before they are
+  // accumulated (in order) so that a thread keeps several requests in flight
+  const int CW = red_cw(v.c), PL = 256 / CW;
+  const int cl = threadIdx.x % CW, pl = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + cl, split = blockIdx.y;
   const long npix = (long)v.n * v.h * v.w;
-  const long p0 = split * npix / RED_SPLITS, p1 = (split + 1) * npix / RED_SPLITS;
+  const int p0 = (int)(split * npix / RED_SPLITS), p1 = (int)((split + 1) * npix / RED_SPLITS);
   double s0 = 0.0, s1 = 0.0;
   if (c < v.c) {
-    const long HW = (long)v.h * v.w;
-    for (long p = p0 + pl; p < p1; p += 4) {
-      long n = p / HW, rem = p - n * HW;
-      long yy = rem / v.w, xx = rem - yy * v.w;
-      float a0, a1;
-      f(n * v.sn + yy * v.sh + xx * v.sw + c, n, yy, xx, c, a0, a1);
-      s0 += a0;
-      s1 += a1;
+    const int HW = v.h * v.w;
+    auto at = [&](int p, float& a0, float& a1) __attribute__((always_inline)) {
+      const int n = p / HW, rem = p - n * HW;
+      const int yy = rem / v.w, xx = rem - yy * v.w;
+      f((long)n * v.sn + (long)yy * v.sh + (long)xx * v.sw + c, (long)n, (long)yy, (long)xx, c, a0, a1);
+    };
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+      float a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) at(p + u * PL, a0[u], a1[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += a0[u]; s1 += a1[u]; }
     }
+    for (; p < p1; p += PL) { float a0, a1; at(p, a0, a1); s0 += a0; s1 += a1; }
   }
   __shared__ double red[2][256];
   red[0][threadIdx.x] = s0;
   red[1][threadIdx.x] = s1;
   __syncthreads();
-  if (threadIdx.x < 64 && c < v.c) {
+  if (threadIdx.x < CW && c < v.c) {
     double t0 = 0.0, t1 = 0.0;
-    for (int k = 0; k < 4; ++k) { t0 += red[0][k * 64 + threadIdx.x]; t1 += red[1][k * 64 + threadIdx.x]; }
+    for (int k = 0; k < PL; ++k) { t0 += red[0][k * CW + threadIdx.x]; t1 += red[1][k * CW + threadIdx.x]; }
     partial[((long)split * v.c + c) * 2] = t0;
     partial[((long)split * v.c + c) * 2 + 1] = t1;
   }
@@ -80,13 +91,13 @@ __global__ void bn_stats_final_kernel(const double* partial, int C, double count
   }
 }
 
-extern "C" size_t mgdt_reduce_workspace_bytes(int c) { return (size_t)RED_SPLITS * c * 2 * sizeof(double); }
+extern "C" size_t mgdt_reduce_workspace_bytes(int c) { return ((size_t)RED_SPLITS * c * 2 + (size_t)c * 2) * sizeof(double); }   // partials + per-channel sums
 
 extern "C" int mgdt_bn_stats_fwd(const mgdt_view* y, float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                  float* running_var, void* ws, int dtype, mgdt_stream s) {
   if (!view_ok(y) || !mean || !rstd || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_stats: null/empty argument");
   if (y->sc != 1) MGDT_FAIL(MGDT_BAD_SHAPE, "bn_stats: NHWC view required");
-  dim3 grid(cdiv(y->c, 64), RED_SPLITS);
+  dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
   MGDT_DISPATCH_DTYPE(dtype, (bn_stats_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*y, (double*)ws)));
   bn_stats_final_kernel<<<cdiv(y->c, 256), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
                                                                      running_mean, running_var);
@@ -147,10 +158,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const mgdt_view gz,
   });
 }
 
+// per-channel totals of the two BN-backward sums (+ the parameter gradients), once, instead of RED_SPLITS loads per element
+__global__ void bn_bwd_final_kernel(const double* partial, int C, double* sums, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int k = 0; k < RED_SPLITS; ++k) { sg += partial[((long)k * C + c) * 2]; sgx += partial[((long)k * C + c) * 2 + 1]; }
+  sums[2 * c] = sg; sums[2 * c + 1] = sgx;
+  if (dbeta) dbeta[c] = (float)sg;
+  if (dgamma) dgamma[c] = (float)sgx;
+}
+
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const mgdt_view gz, const mgdt_view y, const float* mean, const float* rstd, const float* gamma,
-                                    const float* beta, int act, const double* partial, double count, float* dgamma, float* dbeta,
-                                    const mgdt_view dy) {
+                                    const float* beta, int act, const double* sums, double count, const mgdt_view dy) {
   long total = (long)y.n * y.h * y.w * y.c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % y.c);
@@ -159,12 +180,7 @@ __global__ void bn_bwd_apply_kernel(const mgdt_view gz, const mgdt_view y, const
     t /= y.w;
     int h = (int)(t % y.h);
     long n = t / y.h;
-    double sg = 0.0, sgx = 0.0;
-    for (int k = 0; k < RED_SPLITS; ++k) { sg += partial[((long)k * y.c + c) * 2]; sgx += partial[((long)k * y.c + c) * 2 + 1]; }
-    if (n == 0 && h == 0 && w == 0) {
-      if (dbeta) dbeta[c] = (float)sg;
-      if (dgamma) dgamma[c] = (float)sgx;
-    }
+    const double sg = sums[2 * c], sgx = sums[2 * c + 1];
     float v = (float)((const T*)y.p)[n * y.sn + h * y.sh + w * y.sw + c];
     float gzv = (float)((const T*)gz.p)[n * gz.sn + h * gz.sh + w * gz.sw + c];
     float o;
@@ -185,11 +201,13 @@ extern "C" int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const fl
   if (!view_ok(gz) || !view_ok(y) || !view_ok(dy) || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_act_bwd: null/empty argument");
   if (gz->sc != 1 || y->sc != 1 || dy->sc != 1 || gz->c != y->c || dy->c != y->c || gz->n != y->n || gz->h != y->h || gz->w != y->w)
     MGDT_FAIL(MGDT_BAD_SHAPE, "bn_act_bwd: matching NHWC views required");
-  dim3 grid(cdiv(y->c, 64), RED_SPLITS);
+  dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
   long total = (long)y->n * y->h * y->w * y->c;
+  double* sums = (double*)ws + (size_t)RED_SPLITS * y->c * 2;
   MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (double*)ws)));
-  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (const double*)ws,
-                                                                                               (double)y->n * y->h * y->w, dgamma, dbeta, *dy)));
+  bn_bwd_final_kernel<<<cdiv(y->c, 256), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, sums, dgamma, dbeta);
+  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, sums,
+                                                                                               (double)y->n * y->h * y->w, *dy)));
   MGDT_CHECK_LAUNCH("bn_act_bwd");
   return MGDT_OK;
 }
@@ -365,7 +383,7 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
     else conv_wgrad_generic_kernel<float, bf16><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
     if (dbias) {
-      dim3 g2(cdiv(dy->c, 64), RED_SPLITS);
+      dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
       MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
       bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
     }
@@ -378,7 +396,7 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
   long n = (long)dy->c * x->c * k * k;
   wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate);
   if (dbias) {
-    dim3 g2(cdiv(dy->c, 64), RED_SPLITS);
+    dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
     MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
     bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
   }
