@@ -44,7 +44,7 @@ class HipModule(nn.Module):
 
     def _cached(self, key, tensors, build):
         cache = self.__dict__.setdefault('_pk', {})
-        ver = tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+        ver = (ops.PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
         hit = cache.get(key)
         if hit is None or hit[0] != ver:
             hit = (ver, build())

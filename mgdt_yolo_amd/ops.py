@@ -602,7 +602,13 @@ def grad_clip_coef(flat_grad, max_norm):
     return out
 
 
+# Parameters updated by the HIP optimizer kernels change behind torch's back (no tensor version bump): every cache of packed / folded
+# weights carries this epoch in its key and is rebuilt after an optimizer step.
+PARAM_EPOCH = [0]
+
+
 def sgd_step(p, g, buf, wd, lr, momentum, nesterov, first, clip=None):
+    PARAM_EPOCH[0] += 1
     _launch('sgd_step', 'mgdt_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), float(lr), float(momentum), int(nesterov), int(first), ptr(clip), stream())
 
 

@@ -600,3 +600,32 @@ def test_optimizer_step_matches_torch_sgd_and_loss_decreases():
     print('losses', [round(v, 2) for v in losses])
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
     assert tr.state.steps == 9 and not torch.equal(tr.state.ema[:100], tr.state.data[:100])
+
+
+def test_packed_weight_caches_follow_the_hip_optimizer():
+    """The HIP SGD kernel updates parameters behind torch's back; every packed-weight cache must be rebuilt afterwards: the stepped
+    model must compute exactly what a freshly built model with the same state_dict computes."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    cfg = get_config('mspa_c2f_gd_yolov8', 'n', 80)
+    m = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).to(DEV)
+    tr = DetectionTrainer(m, lr0=0.05)
+    batch = seeded_labels(2, 80, seed=1)
+    batch['img'] = (seeded_images(2, 96, 96, seed=2) * 255).round().to(torch.uint8)
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    x = seeded_images(2, 96, 96, seed=5).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        y0 = m(x)[0].clone()
+    m.train()
+    for _ in range(2):
+        tr.step(batch)
+    m.eval()
+    fresh = DetectionModel(cfg, verbose=False).to(DEV)
+    fresh.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    fresh.eval()
+    with torch.no_grad():
+        y1, y2 = m(x)[0], fresh(x)[0]
+    assert not torch.equal(y0, y1), 'two optimizer steps at lr 0.05 must change the output'
+    assert torch.equal(y1, y2)
