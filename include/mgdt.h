@@ -46,6 +46,10 @@ size_t mgdt_conv_packed_bytes(int cin, int cout, int k, int dtype);
 int mgdt_conv_pack(const float* w_oihw, const float* conv_bias, const float* bn_gamma, const float* bn_beta,
                    const float* bn_mean, const float* bn_var, float bn_eps, int cin, int cout, int k, int dtype,
                    void* packed_out, float* bias_out, mgdt_stream s);
+/* Weights of the stride-1 data-gradient convolution: dx = mgdt_conv2d_fwd(x = dy, packed, k, stride 1, y = dx) with
+ * w'[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx] (what autograd's conv backward computes for stride 1, same padding).  cin / cout are
+ * those of the original conv; size the buffer with mgdt_conv_packed_bytes(cout, cin, k, dtype); bias_out: fp32[cin rounded up to 16], zeroed. */
+int mgdt_conv_pack_dgrad(const float* w_oihw, int cin, int cout, int k, int dtype, void* packed_out, float* bias_out, mgdt_stream s);
 
 /* ---- fused convolution (implicit GEMM on MFMA) ------------------------------------------------------------
  * Replaces nn/modules/conv.py:25-42 Conv.forward/forward_fuse (conv2d + folded BN + act), the Bottleneck

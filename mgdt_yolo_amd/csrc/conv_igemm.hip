@@ -16,9 +16,12 @@
 #include "conv_igemm_kernel.h"
 
 // ------------------------------------------------------------------------------------------------ packing
+// `dgrad`: pack the weights of the data-gradient convolution instead - rows = input channels of the original conv, K = (flipped tap,
+// output channel): dx = conv(dy, w'[ci][co][ky][kx] = w[co][ci][KS-1-ky][KS-1-kx]) for stride 1.  Cin / Cout are then those of the
+// dgrad conv (Cin = original cout, Cout = original cin).
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cin, int Cout, int KS,
-                            int CP, int nchunks, int NTtot, T* __restrict__ out) {
+                            int CP, int nchunks, int NTtot, T* __restrict__ out, int dgrad = 0) {
   constexpr int PE = Piece<T>::PE;
   long total = (long)nchunks * NTtot * 64 * PE;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -34,7 +37,8 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
     int cin = cp * PE + j, cout = nb * 16 + r;
     float v = 0.f;
     if (tap < KS * KS && cin < Cin && cout < Cout) {
-      v = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
+      if (dgrad) v = w[(((long)cin * Cout + cout) * KS + (KS - 1 - tap / KS)) * KS + (KS - 1 - tap % KS)];   // original layout [cin=co][cout=ci][ky][kx]
+      else v = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
       if (scale) v *= scale[cout];
     }
     out[i] = (T)v;
@@ -94,6 +98,23 @@ extern "C" int mgdt_conv_pack(const float* w, const float* cb, const float* g, c
   int grid = (int)std::min<long>((total + 255) / 256, 4096);
   MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, g ? scale : nullptr, cin, cout, k, CP, nchunks, NTtot, (T*)packed)));
   MGDT_CHECK_LAUNCH("conv_pack");
+  return MGDT_OK;
+}
+
+// weights of the stride-1 data-gradient convolution (see pack_kernel): cin / cout are those of the ORIGINAL conv; the packed panel is
+// used with mgdt_conv2d_fwd(x = dy, y = dx, k, stride 1); bias_out (cin padded to 16) is zero-filled.
+extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, int dtype, void* packed, float* bias_out, mgdt_stream s) {
+  if (!w || !packed || !bias_out) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_dgrad: null pointer");
+  int CP, nchunks, NTtot;
+  conv_geometry(cout, cin, k, dtype, &CP, &nchunks, &NTtot);       // the dgrad conv maps cout -> cin channels
+  hipStream_t st = (hipStream_t)s;
+  float* scale = (float*)((char*)packed + (size_t)nchunks * NTtot * 1024);
+  const int cpad = NTtot * 16;
+  fold_kernel<<<cdiv(cpad, 64), 64, 0, st>>>(nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cin, cpad, scale, bias_out);
+  long total = (long)nchunks * NTtot * 64 * piece_elems(dtype);
+  int grid = (int)std::min<long>((total + 255) / 256, 4096);
+  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cout, cin, k, CP, nchunks, NTtot, (T*)packed, 1)));
+  MGDT_CHECK_LAUNCH("conv_pack_dgrad");
   return MGDT_OK;
 }
 

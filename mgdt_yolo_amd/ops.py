@@ -480,7 +480,37 @@ def bn_act_bwd(gz, y, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None):
     return dy
 
 
+class _PackedDgrad:
+    """Weights of one conv packed for its stride-1 data gradient (mgdt_conv_pack_dgrad); same fields as PackedConv."""
+    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', 'key', 'owner')
+
+    def __init__(self, weight, k, dtype, key):
+        import weakref
+        self.owner = weakref.ref(weight)      # the address may be recycled by another parameter: the entry is valid for THIS tensor only
+        cout, cin = weight.shape[0], weight.shape[1]
+        code = dtype_code(dtype)
+        self.k, self.cin, self.cout, self.dtype, self.direct, self.groups, self.key = k, cout, cin, dtype, False, 1, key   # a conv cout -> cin
+        self.w = torch.empty(L.lib().mgdt_conv_packed_bytes(cout, cin, k, code), dtype=torch.uint8, device=weight.device)
+        self.bias = torch.empty((cin + 15) // 16 * 16, dtype=torch.float32, device=weight.device)
+        wf = weight.detach().float().contiguous()
+        L.check(L.lib().mgdt_conv_pack_dgrad(ptr(wf), cin, cout, k, code, ptr(self.w), ptr(self.bias), stream()), 'conv_pack_dgrad')
+
+
+_DGRAD_PK = {}
+
+
 def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
+    """dx (+)= d loss / d x of conv(x, weight).  Stride 1 on NHWC maps: the forward MFMA kernel on the flipped / transposed weights
+    (re-packed once per optimizer epoch); otherwise the direct kernel."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if (stride == 1 and (weight.dim() == 2 and k == 1 or weight.dim() == 4 and weight.shape[2] == k) and k in (1, 3) and dx.dtype == dy.dtype
+            and is_nhwc(dx) and cin % 4 == 0
+            and conv_can_mfma(dy, cout, cin, k, 1, 1, dy.dtype)):
+        key = (PARAM_EPOCH[0], weight._version, dy.dtype)
+        pk = _DGRAD_PK.get(weight.data_ptr())
+        if pk is None or pk.owner() is not weight or pk.key != key:
+            pk = _DGRAD_PK[weight.data_ptr()] = _PackedDgrad(weight, k, dy.dtype, key)
+        return conv2d(dy, pk, 1, ACT_NONE, out=dx, r1=dx if accumulate else None)
     _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
     return dx
 
