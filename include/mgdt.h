@@ -49,7 +49,10 @@ int mgdt_conv_pack(const float* w_oihw, const float* conv_bias, const float* bn_
 /* Weights of the stride-1 data-gradient convolution: dx = mgdt_conv2d_fwd(x = dy, packed, k, stride 1, y = dx) with
  * w'[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx] (what autograd's conv backward computes for stride 1, same padding).  cin / cout are
  * those of the original conv; size the buffer with mgdt_conv_packed_bytes(cout, cin, k, dtype); bias_out: fp32[cin rounded up to 16], zeroed. */
-int mgdt_conv_pack_dgrad(const float* w_oihw, int cin, int cout, int k, int dtype, void* packed_out, float* bias_out, mgdt_stream s);
+int mgdt_conv_pack_dgrad(const float* w_oihw, int cin, int cout, int k, int phase, int dtype, void* packed_out, float* bias_out, mgdt_stream s);
+/* phase = -1: stride 1 (above).  phase = 2*py + px in 0..3 (k = 3, stride 2, even input size): the data gradient at input pixels
+ * (2a + py, 2b + px) is a 3x3 same-padding convolution over dy with the taps w[py + 1 - 2*dy'][px + 1 - 2*dx'] that exist:
+ * dx[:, py::2, px::2] = mgdt_conv2d_fwd(x = dy, packed(phase), k = 3, stride 1, y = that strided view). */
 
 /* ---- fused convolution (implicit GEMM on MFMA) ------------------------------------------------------------
  * Replaces nn/modules/conv.py:25-42 Conv.forward/forward_fuse (conv2d + folded BN + act), the Bottleneck

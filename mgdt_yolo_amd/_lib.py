@@ -29,7 +29,7 @@ PROTOTYPES = {
     'mgdt_conv_packed_bytes': (_sz, [_i, _i, _i, _i]),
     'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
-    'mgdt_conv_pack_dgrad': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'mgdt_conv_pack_dgrad': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv_pack_direct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_direct_fwd': (_i, [VP, _i, _vp, _vp, _i, _i, _i, _i, VP, _i, _vp]),
     'mgdt_spr_pool_fwd': (_i, [VP, _vp, _i, _vp]),

@@ -37,7 +37,12 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
     int cin = cp * PE + j, cout = nb * 16 + r;
     float v = 0.f;
     if (tap < KS * KS && cin < Cin && cout < Cout) {
-      if (dgrad) v = w[(((long)cin * Cout + cout) * KS + (KS - 1 - tap / KS)) * KS + (KS - 1 - tap % KS)];   // original layout [cin=co][cout=ci][ky][kx]
+      if (dgrad == 1) v = w[(((long)cin * Cout + cout) * KS + (KS - 1 - tap / KS)) * KS + (KS - 1 - tap % KS)];   // original layout [cin=co][cout=ci][ky][kx]
+      else if (dgrad >= 2) {   // stride-2 phase (py, px) of a 3x3 conv: tap (dy', dx') of the dy grid carries w[ky = py + 1 - 2*dy'][kx = px + 1 - 2*dx'] when that exists
+        const int py = (dgrad - 2) >> 1, px = (dgrad - 2) & 1;
+        const int ky = py + 1 - 2 * (tap / KS - 1), kx = px + 1 - 2 * (tap % KS - 1);
+        v = ((unsigned)ky < 3u && (unsigned)kx < 3u) ? w[(((long)cin * Cout + cout) * 3 + ky) * 3 + kx] : 0.f;
+      }
       else v = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
       if (scale) v *= scale[cout];
     }
@@ -103,8 +108,9 @@ extern "C" int mgdt_conv_pack(const float* w, const float* cb, const float* g, c
 
 // weights of the stride-1 data-gradient convolution (see pack_kernel): cin / cout are those of the ORIGINAL conv; the packed panel is
 // used with mgdt_conv2d_fwd(x = dy, y = dx, k, stride 1); bias_out (cin padded to 16) is zero-filled.
-extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, int dtype, void* packed, float* bias_out, mgdt_stream s) {
+extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, int phase, int dtype, void* packed, float* bias_out, mgdt_stream s) {
   if (!w || !packed || !bias_out) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_dgrad: null pointer");
+  if (phase < -1 || phase > 3 || (phase >= 0 && k != 3)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_pack_dgrad: phase %d (stride-2 phases need k = 3)", phase);
   int CP, nchunks, NTtot;
   conv_geometry(cout, cin, k, dtype, &CP, &nchunks, &NTtot);       // the dgrad conv maps cout -> cin channels
   hipStream_t st = (hipStream_t)s;
@@ -113,7 +119,7 @@ extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, in
   fold_kernel<<<cdiv(cpad, 64), 64, 0, st>>>(nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cin, cpad, scale, bias_out);
   long total = (long)nchunks * NTtot * 64 * piece_elems(dtype);
   int grid = (int)std::min<long>((total + 255) / 256, 4096);
-  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cout, cin, k, CP, nchunks, NTtot, (T*)packed, 1)));
+  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cout, cin, k, CP, nchunks, NTtot, (T*)packed, phase < 0 ? 1 : 2 + phase)));
   MGDT_CHECK_LAUNCH("conv_pack_dgrad");
   return MGDT_OK;
 }

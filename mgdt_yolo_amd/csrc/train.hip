@@ -343,14 +343,15 @@ __global__ void bias_grad_final_kernel(const double* partial, int C, float* db, 
 
 // generic-stride variant (the 3-channel stem reads the NCHW image): one block per weight element, fixed-order tree reduction
 template <typename TX, typename T>
-__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const mgdt_view x, const mgdt_view dy, int KS, int stride, float* __restrict__ dw,
-                                                                 int accumulate) {
-  const int e = blockIdx.x;                       // ((co * Cin + ci) * KS + ky) * KS + kx
+__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const mgdt_view x, const mgdt_view dy, int KS, int stride, float* __restrict__ partial,
+                                                                 long nel) {
+  const int e = blockIdx.x, split = blockIdx.y;   // e = ((co * Cin + ci) * KS + ky) * KS + kx; WG_SPLITS pixel ranges per element
   const int kx = e % KS, ky = (e / KS) % KS, ci = (e / (KS * KS)) % x.c, co = e / (KS * KS * x.c);
   const int pad = KS / 2;
   const long M = (long)dy.n * dy.h * dy.w, HW = (long)dy.h * dy.w;
   double acc = 0.0;
-  for (long p = threadIdx.x; p < M; p += 256) {
+  const long q0 = split * M / WG_SPLITS, q1 = (split + 1) * M / WG_SPLITS;
+  for (long p = q0 + threadIdx.x; p < q1; p += 256) {
     long n = p / HW, rem = p - n * HW;
     int oy = (int)(rem / dy.w), ox = (int)(rem - (long)oy * dy.w);
     int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const mgdt_view
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dw[e] = accumulate ? dw[e] + (float)red[0] : (float)red[0];
+  if (threadIdx.x == 0) partial[(long)split * nel + e] = (float)red[0];
 }
 
 extern "C" size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k) {
@@ -380,8 +381,9 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
   if (x->sc != 1 || x->c % 4 || dy->c % 4) {   // generic path: fp32 input of any layout (the image), no fused x2
     if (x2 && x2->p) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: x2 needs the NHWC path");
     int nel = dy->c * x->c * k * k;
-    if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
-    else conv_wgrad_generic_kernel<float, bf16><<<nel, 256, 0, st>>>(*x, *dy, k, stride, dw_oihw, accumulate);
+    if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
+    else conv_wgrad_generic_kernel<float, bf16><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
+    wgrad_final_kernel<<<cdiv(nel, 256), 256, 0, st>>>((const float*)ws, nel, dw_oihw, accumulate);
     if (dbias) {
       dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
       MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));

@@ -484,7 +484,7 @@ class _PackedDgrad:
     """Weights of one conv packed for its stride-1 data gradient (mgdt_conv_pack_dgrad); same fields as PackedConv."""
     __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', 'key', 'owner')
 
-    def __init__(self, weight, k, dtype, key):
+    def __init__(self, weight, k, dtype, key, phase=-1):
         import weakref
         self.owner = weakref.ref(weight)      # the address may be recycled by another parameter: the entry is valid for THIS tensor only
         cout, cin = weight.shape[0], weight.shape[1]
@@ -493,7 +493,7 @@ class _PackedDgrad:
         self.w = torch.empty(L.lib().mgdt_conv_packed_bytes(cout, cin, k, code), dtype=torch.uint8, device=weight.device)
         self.bias = torch.empty((cin + 15) // 16 * 16, dtype=torch.float32, device=weight.device)
         wf = weight.detach().float().contiguous()
-        L.check(L.lib().mgdt_conv_pack_dgrad(ptr(wf), cin, cout, k, code, ptr(self.w), ptr(self.bias), stream()), 'conv_pack_dgrad')
+        L.check(L.lib().mgdt_conv_pack_dgrad(ptr(wf), cin, cout, k, phase, code, ptr(self.w), ptr(self.bias), stream()), 'conv_pack_dgrad')
 
 
 _DGRAD_PK = {}
@@ -511,6 +511,17 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
         if pk is None or pk.owner() is not weight or pk.key != key:
             pk = _DGRAD_PK[weight.data_ptr()] = _PackedDgrad(weight, k, dy.dtype, key)
         return conv2d(dy, pk, 1, ACT_NONE, out=dx, r1=dx if accumulate else None)
+    if (stride == 2 and k == 3 and weight.dim() == 4 and weight.shape[2] == 3 and dx.dtype == dy.dtype and is_nhwc(dx) and cin % 4 == 0
+            and dx.shape[2] == 2 * dy.shape[2] and dx.shape[3] == 2 * dy.shape[3] and conv_can_mfma(dy, cout, cin, 3, 1, 1, dy.dtype)):
+        # four phases (input-pixel parities), each a 3x3 convolution over dy written to a strided view of dx
+        key = (PARAM_EPOCH[0], weight._version, dy.dtype)
+        pks = _DGRAD_PK.get((weight.data_ptr(), 2))
+        if pks is None or pks[0].owner() is not weight or pks[0].key != key:
+            pks = _DGRAD_PK[(weight.data_ptr(), 2)] = [_PackedDgrad(weight, 3, dy.dtype, key, phase=ph) for ph in range(4)]
+        for ph in range(4):
+            sub = dx[:, :, ph >> 1::2, ph & 1::2]
+            conv2d(dy, pks[ph], 1, ACT_NONE, out=sub, r1=sub if accumulate else None)
+        return dx
     _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
     return dx
 
