@@ -273,16 +273,22 @@ extern "C" int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, 
 // dw[co][ci][ky][kx] = sum_{n,oy,ox} dy[n,oy,ox,co] * (x [+ x2])[n, oy*s-pad+ky, ox*s-pad+kx, ci]
 // block = one tap x 16 couts x 16 cins x one pixel split; 256 threads = 16 (co quad, ci quad) pairs x 16 pixel lanes.
 #define WG_SPLITS 16
+// pixel splits of the NHWC path: more of them for small weight tensors (few (co, ci, tap) blocks) so that the grid still fills the chip;
+// the partial buffer stays <= max(16 splits, 16 MiB)
+static inline int wgrad_splits(int cin, int cout, int k) {
+  const long nel = (long)cin * cout * k * k;
+  return (int)std::max<long>(WG_SPLITS, std::min<long>(256, (4L << 20) / std::max<long>(nel, 1)));
+}
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view x, const mgdt_view x2, const mgdt_view dy, int KS, int stride,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, int nsplit) {
   const int tap = blockIdx.z % (KS * KS), split = blockIdx.z / (KS * KS);
   const int ky = tap / KS, kx = tap % KS, pad = KS / 2;
   const int co0 = blockIdx.x * 16, ci0 = blockIdx.y * 16;
   const int pair = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int coq = co0 + (pair >> 2) * 4, ciq = ci0 + (pair & 3) * 4;
-  const long M = (long)dy.n * dy.h * dy.w, HW = (long)dy.h * dy.w;
-  const long p0 = split * M / WG_SPLITS, p1 = (split + 1) * M / WG_SPLITS;
+  const int M = dy.n * dy.h * dy.w, HW = dy.h * dy.w;
+  const int p0 = (int)((long)split * M / nsplit), p1 = (int)((long)(split + 1) * M / nsplit);
   float acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -290,18 +296,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
   const bool live = coq < dy.c && ciq < x.c;
   if (live) {
-    for (long p = p0 + pl; p < p1; p += 16) {
-      long n = p / HW, rem = p - n * HW;
-      int oy = (int)(rem / dy.w), ox = (int)(rem - (long)oy * dy.w);
-      int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      if ((unsigned)iy >= (unsigned)x.h || (unsigned)ix >= (unsigned)x.w) continue;
-      f32x4 g = load4<T>((const T*)dy.p + n * dy.sn + oy * dy.sh + ox * dy.sw + coq);
-      f32x4 v = load4<T>((const T*)x.p + n * x.sn + iy * x.sh + ix * x.sw + ciq);
-      if (x2.p) v += load4<T>((const T*)x2.p + n * x2.sn + iy * x2.sh + ix * x2.sw + ciq);
+    // four pixels per round: their loads are issued together (zero weight for taps outside the image instead of a branch), then the
+    // 16 FMAs per pixel in pixel order
+    auto fetch = [&](int p, f32x4& g, f32x4& v) __attribute__((always_inline)) {
+      const bool inr = p < p1;
+      const int pp = inr ? p : p0;
+      const int n = pp / HW, rem = pp - n * HW;
+      const int oy = rem / dy.w, ox = rem - oy * dy.w;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      const bool ok = inr && (unsigned)iy < (unsigned)x.h && (unsigned)ix < (unsigned)x.w;
+      const int iyc = ok ? iy : 0, ixc = ok ? ix : 0;
+      g = load4<T>((const T*)dy.p + (long)n * dy.sn + (long)oy * dy.sh + (long)ox * dy.sw + coq);
+      v = load4<T>((const T*)x.p + (long)n * x.sn + (long)iyc * x.sh + (long)ixc * x.sw + ciq);
+      if (x2.p) v += load4<T>((const T*)x2.p + (long)n * x2.sn + (long)iyc * x2.sh + (long)ixc * x2.sw + ciq);
+      if (!ok) g = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    for (int p = p0 + pl; p < p1; p += 64) {
+      f32x4 g[4], v[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int u = 0; u < 4; ++u) fetch(p + u * 16, g[u], v[u]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(g[a], v[b], acc[a][b]);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(g[u][a], v[u][b], acc[a][b]);
     }
   }
   __shared__ float red[16][16][17];
@@ -320,11 +339,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view
   }
 }
 
-__global__ void wgrad_final_kernel(const float* partial, long n, float* dw, int accumulate) {
+__global__ void wgrad_final_kernel(const float* partial, long n, float* dw, int accumulate, int nsplit) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int k = 0; k < WG_SPLITS; ++k) s += partial[(long)k * n + i];
+  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
   dw[i] = accumulate ? dw[i] + s : s;
 }
 
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const mgdt_view
 }
 
 extern "C" size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k) {
-  return std::max((size_t)WG_SPLITS * cin * cout * k * k * sizeof(float), mgdt_reduce_workspace_bytes(cout));
+  return std::max((size_t)wgrad_splits(cin, cout, k) * cin * cout * k * k * sizeof(float), mgdt_reduce_workspace_bytes(cout));
 }
 
 extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
@@ -383,7 +402,7 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     int nel = dy->c * x->c * k * k;
     if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
     else conv_wgrad_generic_kernel<float, bf16><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
-    wgrad_final_kernel<<<cdiv(nel, 256), 256, 0, st>>>((const float*)ws, nel, dw_oihw, accumulate);
+    wgrad_final_kernel<<<cdiv(nel, 256), 256, 0, st>>>((const float*)ws, nel, dw_oihw, accumulate, WG_SPLITS);
     if (dbias) {
       dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
       MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
@@ -393,10 +412,12 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     return MGDT_OK;
   }
   mgdt_view b = (x2 && x2->p) ? *x2 : null_view();
-  dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * WG_SPLITS);
-  MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws)));
+  const int nsplit = wgrad_splits(x->c, dy->c, k);
+  if ((long)dy->n * dy->h * dy->w >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: too many pixels");
+  dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * nsplit);
+  MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
   long n = (long)dy->c * x->c * k * k;
-  wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate);
+  wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
   if (dbias) {
     dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
     MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
