@@ -528,6 +528,16 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
 
 def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
     lib = L.lib()
+    if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype == torch.float32 and x2 is None and not accumulate and x.shape[1] < 4:
+        # the 3-channel image (NCHW): one strided copy into a 4-channel NHWC buffer (4th channel zero) puts the stem on the tiled NHWC kernel;
+        # the generic kernel would scan every pixel once per weight element
+        b, c, h, w = x.shape
+        x4 = new_act(b, 4, h, w, x.dtype, x.device).zero_()
+        copy(x, x4[:, :c])
+        dw4 = torch.empty((dw.shape[0], 4, k, k), dtype=torch.float32, device=x.device)
+        conv_wgrad(x4, dy, k, stride, dw4, dbias=dbias)
+        copy(dw4[:, :c], dw)
+        return
     ws = torch.empty(lib.mgdt_conv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k), dtype=torch.uint8, device=x.device)
     _launch('conv_wgrad', 'mgdt_conv_wgrad', vp(x), vp(x2), vp(dy), k, stride, ptr(dw), ptr(dbias), int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
 
