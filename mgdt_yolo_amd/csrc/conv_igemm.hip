@@ -197,7 +197,7 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   if (NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e ? atoi(e) : 2; }
   int waves = 8;
   auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
-  if (wgs(NT, waves) < 512) waves = 4;                              // small maps: more, smaller tiles
+  // (4-wave workgroups for small maps were tried: 8 waves measured faster on the whole net - fewer, fuller workgroups stage the weight panel less often)
   while (wgs(NT, waves) < 256 && NT > 1 && NT % 2 == 0) NT /= 2;    // ... and split the couts over workgroups
   {   // experiment knob (not part of the ABI)
     const char* e;
