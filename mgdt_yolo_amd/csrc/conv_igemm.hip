@@ -198,7 +198,11 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   int waves = 8;
   auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
   // (4-wave workgroups for small maps were tried: 8 waves measured faster on the whole net - fewer, fuller workgroups stage the weight panel less often)
-  while (wgs(NT, waves) < 256 && NT > 1 && NT % 2 == 0) NT /= 2;    // ... and split the couts over workgroups
+  {
+    const char* e = getenv("MGDT_CONV_MINWG");            // experiment knob (not part of the ABI)
+    const int minwg = e ? atoi(e) : 128;               // measured: 64 -> 1.800, 128 -> 1.791, 256 -> 1.811, 512 -> 1.876 ms per step
+    while (wgs(NT, waves) < minwg && NT > 1 && NT % 2 == 0) NT /= 2;    // ... and split the couts over workgroups
+  }
   {   // experiment knob (not part of the ABI)
     const char* e;
     if ((e = getenv("MGDT_CONV_WAVES"))) waves = atoi(e);
@@ -210,7 +214,9 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
   size_t lds = a.tab_bytes + (size_t)NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * 1024;
-  int gx = std::min(8 * a.T8, waves == 8 ? 512 : 1024), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
+  int gcap = waves == 8 ? 512 : 1024;
+  { const char* e = getenv("MGDT_CONV_GCAP"); if (e) gcap = atoi(e); }
+  int gx = std::min(8 * a.T8, gcap), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
   if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, waves * 64, lds, st);
   return dispatch_igemm<bf16>(a, NT, MT, gx, gy, waves * 64, lds, st);
