@@ -149,12 +149,22 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const TX* __restrict__ x
     }
   }
   TY* yp = y + n * ysn + oy * ysh + ox * ysw + co0;
+  if constexpr (sizeof(TY) == 2) {      // 16 bf16 = two 16-byte stores (four 8-byte ones touch every cache line of the wave four times)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 v;
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = act_apply(acc[q * 4 + j], act);
-    store4<TY>(yp + q * 4, v);
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)act_apply(acc[h * 8 + j], act);
+      *(bf16x8*)(yp + h * 8) = o;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = act_apply(acc[q * 4 + j], act);
+      store4<TY>(yp + q * 4, v);
+    }
   }
 }
 

@@ -337,7 +337,8 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, const float* fc1_w, 
   const size_t lds = (size_t)(c * 5 + groups * hid + 2 * c) * sizeof(float);
   MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8), {
     const long vecs = (long)x->h * x->w * (c / V);
-    const int K = (int)std::max<long>(1, std::min<long>(64, vecs / 2048));
+    static const long per_wg = getenv("MGDT_SPR_VECS") ? atol(getenv("MGDT_SPR_VECS")) : 2048;   // experiment knob: vectors per workgroup
+    const int K = (int)std::max<long>(1, std::min<long>(64, vecs / per_wg));
     spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
                                                                               x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
                                                                               make_fastdiv((uint32_t)x->w));
