@@ -384,9 +384,10 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, ma
     ml = 1 if (multi_label and nc > 1) else 0
     ws_bytes = lib.mgdt_nms_workspace_bytes(b, nc, a, ml, max_nms)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=pred.device)
-    out = torch.zeros(b, max_det, 6, dtype=torch.float32, device=pred.device)
-    kept = torch.zeros(b, max_det, dtype=torch.int32, device=pred.device)
-    counts = torch.zeros(b, dtype=torch.int32, device=pred.device)
+    # rows past counts[i] are never written (and never read: callers slice by counts); counts[i] is written for every image
+    out = torch.empty(b, max_det, 6, dtype=torch.float32, device=pred.device)
+    kept = torch.empty(b, max_det, dtype=torch.int32, device=pred.device)
+    counts = torch.empty(b, dtype=torch.int32, device=pred.device)
     cls_t = None
     if classes is not None:
         cls_t = torch.as_tensor(list(classes), dtype=torch.int32).to(pred.device)
