@@ -110,6 +110,8 @@ int mgdt_tood_layer_attn_fwd(const float* sums, int n, int c, int hw, const floa
  * (mgdt_conv_pack_direct layout), bias fp32[cout] or NULL. */
 int mgdt_dcnv2_fwd(const mgdt_view* x, const mgdt_view* offset_mask, const float* w_gemm, const float* bias, const mgdt_view* y, int dtype,
                    mgdt_stream s);
+/* The same on the MFMA path (bf16, cin % 8 == 0, cout in {16,32,48,64}, no bias): packed_w = mgdt_conv_pack(w, no BN, cin, cout, k = 3, bf16). */
+int mgdt_dcnv2_mfma_fwd(const mgdt_view* x, const mgdt_view* offset_mask, const void* packed_w, const mgdt_view* y, int dtype, mgdt_stream s);
 /* y = x * sigmoid(gate[n,h,w]) (cls_feat * cls_prob, head.py:536); gate: N x H x W x 1 logits. */
 int mgdt_pixel_gate_fwd(const mgdt_view* x, const mgdt_view* gate, const mgdt_view* y, int dtype, mgdt_stream s);
 

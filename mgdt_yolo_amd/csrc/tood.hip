@@ -5,7 +5,7 @@
 // per-(image, channel) input scale, decode) runs on the existing conv / decode kernels.
 #include <algorithm>
 
-#include "common.h"
+#include "conv_igemm_kernel.h"
 
 static inline bool nhwc4(const mgdt_view* v, int dtype) {
   return v->sc == 1 && v->c % 4 == 0 && v->sw % 4 == 0 && v->sh % 4 == 0 && v->sn % 4 == 0 && ((uintptr_t)v->p % (4 * dtype_size(dtype))) == 0;
@@ -218,6 +218,83 @@ __global__ __launch_bounds__(256) void dcnv2_kernel(const T* __restrict__ x, lon
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     if (co0 + j < Cout) yp[j] = (T)acc[j];
+}
+
+// MFMA variant (bf16, cin % 8 == 0, cout % 16 == 0): DCNv2 is the implicit-GEMM convolution with a different activation gather - the
+// K piece (tap, 8 channels) of pixel r is bilinearly sampled at the tap's offset position and multiplied by its mask instead of being
+// read at the integer tap position.  Weights: the ordinary MFMA fragment panel of mgdt_conv_pack (k = 3, no BN), staged in LDS.
+// Lane (r, g) of chunk kc produces piece kc*4 + g of pixel r: four 16-byte corner loads (clamped coordinates, zero weight outside, mmcv's
+// dmcn_im2col_bilinear rules), 8-channel lerp, mask, pack -> B operand; NB MFMAs per chunk.
+template <int NB>
+__global__ __launch_bounds__(256) void dcnv2_mfma_kernel(const bf16* __restrict__ x, long xsn, long xsh, long xsw, const bf16* __restrict__ om, long osn,
+                                                         long osh, long osw, const char* __restrict__ wpk, bf16* __restrict__ y, long ysn, long ysh, long ysw,
+                                                         int N, int H, int W, int Cin, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) char wlm[];  // [nchunks][NB][64][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < nchunks * NB * 64; i += 256) ((uint4*)wlm)[i] = ((const uint4*)wpk)[i];
+  __syncthreads();
+  const long M = (long)N * H * W;
+  const int CP = Cin / 8;
+  for (long tile = blockIdx.x * 4L + wave; tile * 16 < M; tile += gridDim.x * 4L) {
+    const long m = tile * 16 + r;
+    const bool pv = m < M;
+    const long mm = pv ? m : 0;
+    const int n = (int)(mm / ((long)H * W)), rem = (int)(mm - (long)n * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    const bf16* op = om + n * osn + oy * osh + ox * osw;
+    const bf16* xb = x + n * xsn;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int p = kc * 4 + g, tap = p / CP, c0 = (p - tap * CP) * 8;
+      bf16x8 frag;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) frag[e] = (bf16)0.f;
+      if (pv && tap < 9) {
+        const float hy = (float)(oy - 1 + tap / 3) + (float)op[2 * tap], wx = (float)(ox - 1 + tap % 3) + (float)op[2 * tap + 1];
+        if (hy > -1.f && wx > -1.f && hy < (float)H && wx < (float)W) {
+          const float mk = 1.f / (1.f + expf(-(float)op[18 + tap]));
+          const int h0 = (int)floorf(hy), w0 = (int)floorf(wx), h1 = h0 + 1, w1 = w0 + 1;
+          const float lh = hy - (float)h0, lw = wx - (float)w0, hh = 1.f - lh, hw = 1.f - lw;
+          const float c1 = (h0 >= 0 && w0 >= 0) ? hh * hw * mk : 0.f, c2 = (h0 >= 0 && w1 <= W - 1) ? hh * lw * mk : 0.f;
+          const float c3 = (h1 <= H - 1 && w0 >= 0) ? lh * hw * mk : 0.f, c4 = (h1 <= H - 1 && w1 <= W - 1) ? lh * lw * mk : 0.f;
+          const int h0c = max(h0, 0), w0c = max(w0, 0), h1c = min(h1, H - 1), w1c = min(w1, W - 1);
+          const bf16x8 v1 = *(const bf16x8*)(xb + h0c * xsh + w0c * xsw + c0), v2 = *(const bf16x8*)(xb + h0c * xsh + w1c * xsw + c0);
+          const bf16x8 v3 = *(const bf16x8*)(xb + h1c * xsh + w0c * xsw + c0), v4 = *(const bf16x8*)(xb + h1c * xsh + w1c * xsw + c0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) frag[e] = (bf16)(c1 * (float)v1[e] + c2 * (float)v2[e] + c3 * (float)v3[e] + c4 * (float)v4[e]);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mma(*(const bf16x8*)(wlm + ((size_t)(kc * NB + nb) * 64 + lane) * 16), frag, acc[nb]);
+    }
+    if (pv) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) store4<bf16>(y + n * ysn + oy * ysh + ox * ysw + nb * 16 + 4 * g, acc[nb]);
+    }
+  }
+}
+
+/* DCNv2 on the matrix cores: packed_w from mgdt_conv_pack(w, NULL, NULL bn, cin, cout, k = 3, bf16) (no bias: DyDCNv2 has a norm). */
+extern "C" int mgdt_dcnv2_mfma_fwd(const mgdt_view* x, const mgdt_view* offset_mask, const void* packed_w, const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(offset_mask) || !view_ok(y) || !packed_w) MGDT_FAIL(MGDT_BAD_ARG, "dcnv2_mfma: null/empty argument");
+  if (dtype != MGDT_BF16 || x->c % 8 || y->c % 16 || y->c > 64 || x->sc != 1 || y->sc != 1 || offset_mask->sc != 1 || offset_mask->c < 27 || x->n != y->n ||
+      x->h != y->h || x->w != y->w || offset_mask->n != x->n || offset_mask->h != x->h || offset_mask->w != x->w || x->sw % 8 || x->sh % 8 || x->sn % 8 ||
+      (uintptr_t)x->p % 16 || y->sw % 4 || y->sh % 4 || y->sn % 4 || (uintptr_t)y->p % 8)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "dcnv2_mfma: bf16 NHWC views, cin %% 8 == 0, cout in {16, 32, 48, 64}, offset_mask with >= 27 channels");
+  const int nchunks = (9 * (x->c / 8) + 3) / 4, NB = y->c / 16;
+  const long M = (long)x->n * x->h * x->w;
+  const int grid = (int)std::min<long>(cdiv(M, 64), 2048);
+  const size_t lds = (size_t)nchunks * NB * 1024;
+  if (lds > 64 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "dcnv2_mfma: weight panel %zu B does not fit", lds);
+#define DCN_L(B) dcnv2_mfma_kernel<B><<<grid, 256, lds, (hipStream_t)s>>>((const bf16*)x->p, x->sn, x->sh, x->sw, (const bf16*)offset_mask->p, offset_mask->sn, \
+                                                                         offset_mask->sh, offset_mask->sw, (const char*)packed_w, (bf16*)y->p, y->sn, y->sh, y->sw, \
+                                                                         x->n, x->h, x->w, x->c, nchunks)
+  switch (NB) { case 1: DCN_L(1); break; case 2: DCN_L(2); break; case 3: DCN_L(3); break; default: DCN_L(4); break; }
+#undef DCN_L
+  MGDT_CHECK_LAUNCH("dcnv2_mfma_fwd");
+  return MGDT_OK;
 }
 
 extern "C" int mgdt_dcnv2_fwd(const mgdt_view* x, const mgdt_view* offset_mask, const float* w_gemm, const float* bias, const mgdt_view* y, int dtype,

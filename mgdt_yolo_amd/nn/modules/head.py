@@ -234,7 +234,12 @@ class DyDCNv2(HipModule):
         cw = self.conv.weight
         wg = self._cached('gemm', [cw], lambda: cw.detach().float().permute(2, 3, 1, 0).reshape(9 * cw.shape[1], cw.shape[0]).contiguous())
         b = None if self.conv.bias is None else self.conv.bias.detach().float()
-        y = ops.dcnv2(x, offset_mask, wg, b, cw.shape[0])
+        if (b is None and x.dtype == torch.bfloat16 and offset_mask.dtype == x.dtype and cw.shape[1] % 8 == 0 and cw.shape[0] % 16 == 0 and cw.shape[0] <= 64
+                and ops.is_nhwc(x) and ops.is_nhwc(offset_mask)):
+            pk = self._cached('mfma', [cw], lambda: ops.PackedConv(cw, None, None, 3, torch.bfloat16))     # the ordinary fragment panel of a 3x3 conv
+            y = ops.dcnv2_mfma(x, offset_mask, pk)
+        else:
+            y = ops.dcnv2(x, offset_mask, wg, b, cw.shape[0])
         if not self.with_norm:
             return y
         return ops.groupnorm(y, self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.num_groups, self.norm.eps, act, out=y)

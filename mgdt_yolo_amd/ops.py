@@ -354,6 +354,14 @@ def dcnv2(x, offset_mask, w_gemm, bias, cout):
     return out
 
 
+def dcnv2_mfma(x, offset_mask, pk):
+    """DCNv2 on the MFMA path (bf16): pk = PackedConv(weight, None, None, 3, bfloat16)."""
+    b, _, h, w = x.shape
+    out = new_act(b, pk.cout, h, w, x.dtype, x.device)
+    _launch('dcnv2_mfma_fwd', 'mgdt_dcnv2_mfma_fwd', vp(x), vp(offset_mask), ptr(pk.w), vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
 def pixel_gate(x, gate, out=None):
     out = like(x) if out is None else out
     _launch('pixel_gate_fwd', 'mgdt_pixel_gate_fwd', vp(x), vp(gate), vp(out), dtype_code(x.dtype), stream())

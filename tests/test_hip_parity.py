@@ -188,6 +188,23 @@ def test_dcnv2_matches_oracle_restatement():
     np.testing.assert_allclose(to_nchw(y), ref.numpy(), atol=1e-4, rtol=1e-4)
 
 
+def test_dcnv2_mfma_matches_oracle_restatement():
+    """bf16 DCNv2 on the matrix cores (bilinear-sampled B operand) vs the restatement evaluated on the same bf16-rounded operands."""
+    from mgdt_yolo_amd import ops
+    from oracle import tood
+    g = torch.Generator().manual_seed(6)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(2, 32, 14, 19, generator=g))
+    om = bf(torch.cat([torch.randn(2, 18, 14, 19, generator=g) * 2.5, torch.randn(2, 10, 14, 19, generator=g)], 1))
+    w = bf(torch.randn(48, 32, 3, 3, generator=g) / 17)
+    ref = tood.modulated_deform_conv3x3(x, om[:, :18], om[:, 18:27].sigmoid(), w)
+    nh = lambda t: t.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    pk = ops.PackedConv(w.to(DEV), None, None, 3, torch.bfloat16)
+    y = ops.dcnv2_mfma(nh(x), nh(om), pk)
+    err = (y.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-2, err
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_toodhead_matches_oracle_restatement(dtype):
     """Whole task-aligned head vs oracle/tood.py on seeded weights.  PARITY UNPINNED (no reference run possible: mmcv absent)."""
