@@ -1101,7 +1101,17 @@ extern "C" int mgdt_detect_decode_fwd(const mgdt_view* feat, int reg_max, int nc
     MGDT_FAIL(MGDT_BAD_SHAPE, "detect_decode: c=%d reg_max=%d nc=%d a_off=%d a_total=%d", feat->c, reg_max, nc, a_off, a_total);
   const int no = feat->c;
   size_t lds = (size_t)DEC_A * (no + 1) * sizeof(float);
-  if (vec4_ok(feat, dtype) && lds <= 64 * 1024) {
+  if (vec4_ok(feat, dtype) && lds <= 144 * 1024) {
+    if (lds > 64 * 1024) {      // reg_max = 16 heads (TOODHead): the transposed tile needs more than the default dynamic LDS limit
+      static bool attr_set = false;
+      if (!attr_set) {
+        for (const void* k : {(const void*)detect_decode_tile_kernel<float>, (const void*)detect_decode_tile_kernel<bf16>}) {
+          hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+          if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "detect_decode: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        attr_set = true;
+      }
+    }
     dim3 grid(cdiv((long)feat->h * feat->w, DEC_A), feat->n);
     MGDT_DISPATCH_DTYPE(dtype, (detect_decode_tile_kernel<T><<<grid, 256, lds, (hipStream_t)s>>>((const T*)feat->p, feat->sn, feat->sh, feat->sw, feat->h, feat->w,
                                                                                                  reg_max, nc, stride, a_off, a_total, y)));

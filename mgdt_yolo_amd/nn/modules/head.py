@@ -194,12 +194,13 @@ class TaskDecomposition(HipModule):
         self.sigmoid = nn.Sigmoid()
         self.reduction_conv = _ConvModuleBias(self.in_channels, feat_channels)
 
-    def forward(self, feat, avg_feat=None):
+    def forward(self, feat, sums=None):
+        """`sums` = sum_hw feat per (image, channel) (ops.nc_reduce), shared by the two decompositions like the reference's avg_feat."""
         f32 = lambda t: t.detach().float().reshape(t.shape[0], -1).contiguous()
         la = self._cached('la', [self.la_conv1.weight, self.la_conv1.bias, self.la_conv2.weight, self.la_conv2.bias],
                           lambda: (f32(self.la_conv1.weight), self.la_conv1.bias.detach().float().contiguous(), f32(self.la_conv2.weight),
                                    self.la_conv2.bias.detach().float().contiguous()))
-        scale = ops.tood_layer_attn(feat, la[0], la[1], la[2], la[3], self.stacked_convs)
+        scale = ops.tood_layer_attn(feat, la[0], la[1], la[2], la[3], self.stacked_convs, sums=sums)
         rc = self.reduction_conv.conv
         dt = self.out_dtype(feat)
         # as written in the reference the bmm path uses only `.conv.weight`: reduction_conv's bias parameter is never added (head.py:117-127)
@@ -299,8 +300,9 @@ class TOODHead(Detect):
             feat = ops.new_act(b, 2 * half, h, w, dt, xi.device)        # torch.cat(stack_res_list) = two channel slots
             self.share_conv[0](xi, out=feat[:, :half])
             self.share_conv[1](feat[:, :half], out=feat[:, half:])
-            cls_feat = self.cls_decomp(feat)                            # both decompositions share avg_feat = GAP(feat)
-            reg_feat = self.reg_decomp(feat)
+            sums = ops.nc_reduce(feat)                                  # both decompositions share avg_feat = GAP(feat) (head.py:516)
+            cls_feat = self.cls_decomp(feat, sums)
+            reg_feat = self.reg_decomp(feat, sums)
             om = self._bias_conv(self.spatial_conv_offset, feat, ops.ACT_NONE, dt, pad_to=28)     # 18 offsets | 9 mask logits | pad
             reg_feat = self.DyDCNV2(reg_feat, om, act=ops.ACT_RELU)      # F.relu(reg_feat) of head.py:537 folded into the GroupNorm pass
             prob = self._bias_conv(self.cls_prob_conv2, self._bias_conv(self.cls_prob_conv1, feat, ops.ACT_RELU, dt), ops.ACT_NONE, dt)

@@ -338,10 +338,10 @@ def groupnorm(x, gamma, beta, groups, eps, act, out=None):
     return out
 
 
-def tood_layer_attn(feat, w1, b1, w2, b2, stacked):
+def tood_layer_attn(feat, w1, b1, w2, b2, stacked, sums=None):
     """TaskDecomposition's layer attention as a per-(image, input channel) scale fp32 [B, C] for the reduction conv."""
     b, c, h, w = feat.shape
-    sums = nc_reduce(feat)
+    sums = nc_reduce(feat) if sums is None else sums
     scale = torch.empty(b, c, dtype=torch.float32, device=feat.device)
     _launch('tood_layer_attn_fwd', 'mgdt_tood_layer_attn_fwd', ptr(sums), b, c, h * w, ptr(w1), ptr(b1), ptr(w2), ptr(b2), w1.shape[0], stacked, ptr(scale), stream())
     return scale
