@@ -184,6 +184,13 @@ int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, floa
                  int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
                  int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s);
 
+/* ---- validator matching: DetectionValidator._process_batch, yolo/v8/detect/val.py:152-175, for a batch ----------
+ * det [n][max_det][6] (x1,y1,x2,y2,conf,cls; the layout mgdt_nms_fwd writes) with ndet[n] valid rows, labels [n][max_lab][5]
+ * (cls,x1,y1,x2,y2 in the same pixel frame) with nlab[n] valid rows, iouv[n_iou] ascending IoU levels (n_iou <= 16).
+ * correct [n][max_det][n_iou] uint8: 1 where the detection is a true positive at that level (rows past ndet are 0). */
+int mgdt_val_match_fwd(const float* det, const int32_t* ndet, int n, int max_det, const float* labels, const int32_t* nlab, int max_lab,
+                       const float* iouv, int n_iou, uint8_t* correct, mgdt_stream s);
+
 /* ---- v8DetectionLoss: assigner + BCE/CIoU/DFL + gradient w.r.t. the head maps -----------------------------------------
  * yolo/utils/loss.py:108-208 (v8DetectionLoss.__call__, BboxLoss :56-89), yolo/utils/tal.py:56-353
  * (HeuristicPositiveSampleAssigner_v1 -> TaskAlignedAssigner, topk 10, alpha = 0.5*(100 - call_count/161)/100, beta 8),

@@ -57,6 +57,7 @@ PROTOTYPES = {
     'mgdt_dcnv2_fwd': (_i, [VP, VP, _vp, _vp, VP, _i, _vp]),
     'mgdt_dcnv2_mfma_fwd': (_i, [VP, VP, _vp, VP, _i, _vp]),
     'mgdt_pixel_gate_fwd': (_i, [VP, VP, VP, _i, _vp]),
+    'mgdt_val_match_fwd': (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
     'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),

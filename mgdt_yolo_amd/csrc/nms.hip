@@ -352,3 +352,65 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   MGDT_CHECK_LAUNCH("nms_fwd");
   return MGDT_OK;
 }
+
+// ================================================================================================ validator matching
+// DetectionValidator._process_batch (yolo/v8/detect/val.py:152-175) for a whole batch: one workgroup per image.
+//   iou[l][d] = box_iou(labels, detections) (metrics.py:52-72, eps 1e-7 in the union; this file is built with -ffp-contract=off)
+//   per IoU level t: best[d] = label with the largest IoU among {iou >= level, same class};  a label keeps the LOWEST-INDEX detection that
+//   chose it (np.unique(det) then np.unique(label) without the re-sort, as the fork is written);  correct[d][t] = d is kept.
+// Exact IoU ties between two labels of one detection (numpy's unstable argsort decides in the reference) resolve to the lower label index.
+#define VM_T 16      // max IoU levels
+__global__ __launch_bounds__(256) void val_match_kernel(const float* __restrict__ det, const int32_t* __restrict__ ndet, int max_det,
+                                                        const float* __restrict__ lab, const int32_t* __restrict__ nlab, int max_lab,
+                                                        const float* __restrict__ iouv, int T, uint8_t* __restrict__ correct) {
+  extern __shared__ int winner[];     // [T][max_lab]: lowest detection index that chose the label
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int nd = min(ndet[img], max_det), nl = min(nlab[img], max_lab);
+  const float* D = det + (long)img * max_det * 6;
+  const float* L = lab + (long)img * max_lab * 5;
+  uint8_t* C = correct + (long)img * max_det * T;
+  for (int i = tid; i < T * max_lab; i += 256) winner[i] = 0x7fffffff;
+  __syncthreads();
+  for (int d0 = 0; d0 < max_det; d0 += 256) {     // uniform trip count: barriers inside
+    const int d = d0 + tid;
+    int best[VM_T];
+    float bestv[VM_T];
+#pragma unroll
+    for (int t = 0; t < VM_T; ++t) { best[t] = -1; bestv[t] = -1.f; }
+    if (d < nd) {
+      const float x1 = D[d * 6], y1 = D[d * 6 + 1], x2 = D[d * 6 + 2], y2 = D[d * 6 + 3], cls = D[d * 6 + 5];
+      const float area_d = (x2 - x1) * (y2 - y1);
+      for (int l = 0; l < nl; ++l) {
+        if (L[l * 5] != cls) continue;
+        const float lx1 = L[l * 5 + 1], ly1 = L[l * 5 + 2], lx2 = L[l * 5 + 3], ly2 = L[l * 5 + 4];
+        const float iw = fmaxf(fminf(lx2, x2) - fmaxf(lx1, x1), 0.f), ih = fmaxf(fminf(ly2, y2) - fmaxf(ly1, y1), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / ((lx2 - lx1) * (ly2 - ly1) + area_d - inter + 1e-7f);
+#pragma unroll
+        for (int t = 0; t < VM_T; ++t)
+          if (t < T && iou >= iouv[t] && iou > bestv[t]) { bestv[t] = iou; best[t] = l; }
+      }
+#pragma unroll
+      for (int t = 0; t < VM_T; ++t)
+        if (t < T && best[t] >= 0) atomicMin(&winner[t * max_lab + best[t]], d);
+    }
+    __syncthreads();
+    // detections of later rounds have larger indices: a winner found in this round is final
+    if (d < max_det) {
+#pragma unroll
+      for (int t = 0; t < VM_T; ++t)
+        if (t < T) C[d * T + t] = (d < nd && best[t] >= 0 && winner[t * max_lab + best[t]] == d) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mgdt_val_match_fwd(const float* det, const int32_t* ndet, int n, int max_det, const float* labels, const int32_t* nlab, int max_lab,
+                                  const float* iouv, int n_iou, uint8_t* correct, mgdt_stream s) {
+  if (!det || !ndet || !labels || !nlab || !iouv || !correct) MGDT_FAIL(MGDT_BAD_ARG, "val_match: null pointer");
+  if (n < 1 || max_det < 1 || max_lab < 1 || n_iou < 1 || n_iou > VM_T || (size_t)n_iou * max_lab * sizeof(int) > 64 * 1024)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "val_match: n=%d max_det=%d max_lab=%d n_iou=%d (<= %d levels, levels*max_lab <= 16384)", n, max_det, max_lab, n_iou, VM_T);
+  val_match_kernel<<<n, 256, (size_t)n_iou * max_lab * sizeof(int), (hipStream_t)s>>>(det, ndet, max_det, labels, nlab, max_lab, iouv, n_iou, correct);
+  MGDT_CHECK_LAUNCH("val_match_fwd");
+  return MGDT_OK;
+}

@@ -405,6 +405,17 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, ma
     return out, kept, counts
 
 
+def val_match(det, ndet, labels, nlab, iouv):
+    """Validator matching for a batch (mgdt_val_match_fwd): det (B, max_det, 6) fp32 + ndet (B,) int32 as returned by `nms`, labels
+    (B, max_lab, 5) fp32 [cls, x1, y1, x2, y2] + nlab (B,) int32, iouv (T,) fp32 -> correct (B, max_det, T) bool."""
+    _need_gpu(det)
+    b, md, _ = det.shape
+    ml = labels.shape[1]
+    correct = torch.empty(b, md, iouv.numel(), dtype=torch.uint8, device=det.device)
+    _launch('val_match_fwd', 'mgdt_val_match_fwd', ptr(det), ptr(ndet), b, md, ptr(labels), ptr(nlab), ml, ptr(iouv), iouv.numel(), ptr(correct), stream())
+    return correct.view(torch.bool)
+
+
 # ------------------------------------------------------------------ detection loss (assigner + BCE/CIoU/DFL)
 def _view_array(ts):
     views = [view(t) for t in ts]

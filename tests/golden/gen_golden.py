@@ -180,8 +180,33 @@ def nms(models):
     save('nms', **arrs)
 
 
+# ------------------------------------------------------------------ validator matching (yolo/v8/detect/val.py:152-175)
+def val_match():
+    """Runs the reference's DetectionValidator._process_batch.  Importing yolo/v8/detect/val.py pulls in the whole dataset / plotting stack
+    (cv2 constants, torchvision.datasets), so the method is taken out of the class with `ast` and executed as is, bound to the reference's
+    own `box_iou` - reference code running, nothing restated here."""
+    import ast
+    from inputs import VAL_MATCH_CASES, val_match_inputs
+    src = open('/root/reference/yolo/v8/detect/val.py').read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == 'DetectionValidator')
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == '_process_batch')
+    env = {'np': np, 'torch': torch, 'box_iou': ns.metrics.box_iou}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'ref:_process_batch', 'exec'), env)
+    me = types.SimpleNamespace(iouv=torch.linspace(0.5, 0.95, 10))
+    arrs = {'iouv': me.iouv.numpy()}
+    for seed, nd, nl in VAL_MATCH_CASES:
+        det, lab = val_match_inputs(seed, nd, nl)
+        if nd == 0 or nl == 0:
+            correct = np.zeros((nd, 10), bool)       # val.py:107-113: the caller never reaches _process_batch for empty sides
+        else:
+            correct = env['_process_batch'](me, torch.from_numpy(det), torch.from_numpy(lab)).numpy()
+        arrs[f'c{seed}'] = correct
+        print('val_match', seed, det.shape, lab.shape, 'true positives per IoU level', correct.sum(0).tolist())
+    save('val_match', **arrs)
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms']
+    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match']
     models = {}
     if 'e2e' in what or 'nms' in what:
         for tag, yname in E2E_MODELS.items():
@@ -196,3 +221,5 @@ if __name__ == '__main__':
         loss()
     if 'nms' in what:
         nms(models)
+    if 'val_match' in what:
+        val_match()

@@ -81,3 +81,28 @@ NMS_CASES = (('pred', dict(conf_thres=0.25, iou_thres=0.7)),
 E2E_SHAPES = [(2, 160, 160), (1, 96, 160), (1, 640, 640)]
 E2E_MODELS = {'mspa_c2f_gd_n': 'mspa_c2f_gd_yolov8', 'yolov8_n': 'yolov8'}
 IMG_SEED = 7
+
+
+# ---------------------------------------------------------------- validator matching: detections vs labels of one image
+VAL_MATCH_CASES = [(0, 40, 6), (1, 300, 20), (2, 7, 1), (3, 120, 33), (4, 5, 0), (5, 0, 4)]   # (seed, n_det, n_labels)
+
+
+def val_match_inputs(seed, n_det, n_lab, nc=5):
+    """detections (n_det, 6) [x1,y1,x2,y2,conf,cls] sorted by conf like NMS output, labels (n_lab, 5) [cls,x1,y1,x2,y2] in pixels.
+    Two thirds of the detections are jittered copies of label boxes (all IoU levels get matches), classes partly wrong."""
+    r = np.random.default_rng([seed, 777])
+    c = r.uniform(60, 580, (n_lab, 2)); wh = r.uniform(20, 160, (n_lab, 2))
+    lab = np.concatenate([r.integers(0, nc, (n_lab, 1)).astype(np.float32), c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    det = np.zeros((n_det, 6), np.float32)
+    for i in range(n_det):
+        if n_lab and i % 3 != 2:
+            j = int(r.integers(0, n_lab))
+            jit = r.normal(0, r.choice([1.0, 4.0, 12.0]), 4)
+            det[i, :4] = lab[j, 1:] + jit
+            det[i, 5] = lab[j, 0] if r.random() < 0.8 else float(r.integers(0, nc))
+        else:
+            cc = r.uniform(60, 580, 2); ww = r.uniform(20, 160, 2)
+            det[i, :4] = np.concatenate([cc - ww / 2, cc + ww / 2])
+            det[i, 5] = float(r.integers(0, nc))
+    det[:, 4] = np.sort(r.uniform(0.001, 1.0, n_det))[::-1]
+    return det.astype(np.float32), lab

@@ -646,3 +646,36 @@ def test_packed_weight_caches_follow_the_hip_optimizer():
         y1, y2 = m(x)[0], fresh(x)[0]
     assert not torch.equal(y0, y1), 'two optimizer steps at lr 0.05 must change the output'
     assert torch.equal(y1, y2)
+
+
+def test_validator_matching_bit_exact(golden):
+    """mgdt_val_match_fwd (one workgroup per image, whole batch in one launch) vs the reference's _process_batch fixtures and, on a larger
+    random batch, vs the oracle: the boolean true-positive matrix is compared bit for bit."""
+    from mgdt_yolo_amd import ops
+    from oracle import val as OV
+    g = golden('val_match')
+    iouv = torch.from_numpy(g['iouv'])
+    cases = [(seed, *GI.val_match_inputs(seed, nd, nl)) for seed, nd, nl in GI.VAL_MATCH_CASES]
+    cases += [(100 + k, *GI.val_match_inputs(100 + k, nd, nl)) for k, (nd, nl) in enumerate([(300, 64), (257, 3), (31, 90), (300, 1)])]
+    b, md, ml = len(cases), 300, 96
+    det = torch.zeros(b, md, 6); lab = torch.zeros(b, ml, 5)
+    ndet = torch.zeros(b, dtype=torch.int32); nlab = torch.zeros(b, dtype=torch.int32)
+    for i, (_, d, l) in enumerate(cases):
+        det[i, :len(d)] = torch.from_numpy(d); lab[i, :len(l)] = torch.from_numpy(l)
+        ndet[i], nlab[i] = len(d), len(l)
+    correct = ops.val_match(det.to(DEV), ndet.to(DEV), lab.to(DEV), nlab.to(DEV), iouv.to(DEV)).cpu().numpy()
+    for i, (seed, d, l) in enumerate(cases):
+        ref = g[f'c{seed}'] if f'c{seed}' in g else OV.process_batch(torch.from_numpy(d), torch.from_numpy(l), iouv)
+        assert np.array_equal(correct[i, :len(d)], ref), seed
+        assert not correct[i, len(d):].any()
+
+
+def test_validator_surface_matches_reference_call_form(golden):
+    """DetectionValidator._process_batch(detections, labels): the reference's per-image call form (val.py:152)."""
+    from mgdt_yolo_amd.yolo.v8.detect import DetectionValidator
+    g = golden('val_match')
+    v = DetectionValidator(DEV)
+    for seed, nd, nl in GI.VAL_MATCH_CASES:
+        det, lab = GI.val_match_inputs(seed, nd, nl)
+        c = v._process_batch(torch.from_numpy(det).to(DEV), torch.from_numpy(lab).to(DEV))
+        assert c.dtype == torch.bool and c.device.type == 'cuda' and np.array_equal(c.cpu().numpy(), g[f'c{seed}']), seed

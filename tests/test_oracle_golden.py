@@ -183,3 +183,15 @@ def test_greedy_nms_properties():
         assert (iou_d[j][keep < d] > 0.5 - 1e-6).any()
     assert np.array_equal(ON.greedy_nms(b[keep], 0.5), np.arange(len(keep)))   # idempotent
     assert len(ON.greedy_nms(np.zeros((0, 4), np.float32), 0.5)) == 0
+
+
+def test_validator_matching_matches_reference(golden):
+    """oracle.val.process_batch vs the reference's own DetectionValidator._process_batch (fixture val_match.npz), all six cases bit-exact."""
+    from oracle import val as OV
+    g = golden('val_match')
+    iouv = torch.from_numpy(g['iouv'])
+    assert np.array_equal(g['iouv'], torch.linspace(0.5, 0.95, 10).numpy())
+    for seed, nd, nl in GI.VAL_MATCH_CASES:
+        det, lab = GI.val_match_inputs(seed, nd, nl)
+        got = OV.process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv)
+        assert got.shape == g[f'c{seed}'].shape and np.array_equal(got, g[f'c{seed}']), seed
