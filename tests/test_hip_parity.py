@@ -679,3 +679,25 @@ def test_validator_surface_matches_reference_call_form(golden):
         det, lab = GI.val_match_inputs(seed, nd, nl)
         c = v._process_batch(torch.from_numpy(det).to(DEV), torch.from_numpy(lab).to(DEV))
         assert c.dtype == torch.bool and c.device.type == 'cuda' and np.array_equal(c.cpu().numpy(), g[f'c{seed}']), seed
+
+
+def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
+    """The bench configuration (B=8 of the 32, 640x640, bf16) with every fused kernel of this round switched off (conv / GRN / inject launch
+    chains) vs on: same model, same input.  Differences are bf16 re-association only; both variants are bf16 forwards, each within the
+    stated bf16 tolerance of the fp32 reference (conf 0.05, boxes 1.5 px), so they may differ from each other by up to twice that at the
+    worst of 4 M scores; the mean difference is two orders of magnitude smaller."""
+    from mgdt_yolo_amd import ops
+    m = build_model('mspa_c2f_gd_yolov8', torch.bfloat16)
+    x = seeded_images(8, 640, 640, seed=100).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        y_on = m(x)[0].float()
+        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = False
+        try:
+            y_off = m(x)[0].float()
+        finally:
+            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = True
+    assert not torch.equal(y_on, y_off)                      # the switches really changed the launch sequence
+    dc, db = (y_on[:, 4:] - y_off[:, 4:]).abs(), (y_on[:, :4] - y_off[:, :4]).abs()
+    print(f'fused vs chains: conf max {dc.max().item():.4f} mean {dc.mean().item():.5f}; box max {db.max().item():.3f} px mean {db.mean().item():.4f}')
+    assert dc.max().item() < 0.1 and dc.mean().item() < 2e-3
+    assert db.max().item() < 3.0 and db.mean().item() < 0.2
