@@ -6,13 +6,13 @@
 // normalise with the biased batch variance, update running_var with the unbiased one.
 #include "common.h"
 
-#define RED_SPLITS 128
+#define RED_SPLITS 512
 // channel lanes of a reduction block: the whole channel range when it is narrow, so that all 256 threads have pixels to walk
 static __host__ __device__ inline int red_cw(int c) { return c > 32 ? 64 : c > 16 ? 32 : c > 8 ? 16 : c > 4 ? 8 : 4; }
 
 __device__ __forceinline__ float act_fwd(float u, int act) {
   switch (act) {
-    case MGDT_ACT_SILU: return u / (1.f + expf(-u));
+    case MGDT_ACT_SILU: return u * fast_sigmoid(u);     // hardware exp2 / rcp (~1 ulp each), as the inference epilogues
     case MGDT_ACT_RELU: return fmaxf(u, 0.f);
     case MGDT_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
     default: return u;
@@ -20,7 +20,7 @@ __device__ __forceinline__ float act_fwd(float u, int act) {
 }
 __device__ __forceinline__ float act_grad(float u, int act) {
   switch (act) {
-    case MGDT_ACT_SILU: { float s = 1.f / (1.f + expf(-u)); return s * (1.f + u * (1.f - s)); }
+    case MGDT_ACT_SILU: { float s = fast_sigmoid(u); return s * (1.f + u * (1.f - s)); }
     case MGDT_ACT_RELU: return u > 0.f ? 1.f : 0.f;
     case MGDT_ACT_GELU: return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
     default: return 1.f;
