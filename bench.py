@@ -1,37 +1,45 @@
 """Headline benchmark: images/sec @640x640, batch 32 per GPU, MSPA-C2f + GD-neck YOLOv8n (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W] [--dtype bf16|f32] [--mode infer|train]
 
-A step = one pass of the hot path over one resident batch: detection forward (all layers, HIP kernels through the
-C ABI) + Detect decode + batched NMS (predict settings conf 0.25 / iou 0.7), replayed from a hipGraph.
-Inputs (fp32 NCHW images) are already in HBM when the timed region starts.  Inference shards over the batch with
-no collective: N ranks = N replicas with disjoint batches ("weak" scaling); the only collective is the MAX of
-the per-rank times.  Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timed) and
-`cpu_baseline` (the CPU oracle - a port of the reference's path - timed on this box's host cores).
+N > 1 without a launcher: this process starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD before it
+touches the GPU and exits with the child's code (one rank per GPU over RCCL); under torchrun the ranks read RANK / WORLD_SIZE.
+
+mode infer (default, the headline): a step = one pass of the hot path over one resident batch: detection forward (all layers, HIP
+kernels through the C ABI) + Detect decode + batched NMS (predict settings conf 0.25 / iou 0.7), replayed from a hipGraph.  R = 8
+different batches (> 256 MiB together, so the Infinity Cache cannot hold the inputs) are resident in HBM before the timed region and
+are cycled through, one hipGraph per batch.  Inference shards over the batch with no collective: N ranks = N replicas with disjoint
+batches ("weak" scaling); the only collective is the MAX of the per-rank times.
+mode train (BASELINE configs[2]): a step = DetectionTrainer.step on a resident uint8 batch with synthetic labels: train-mode forward,
+fused assigner + loss, HIP reverse pass, bucketed RCCL all-reduce of the flat gradient buffer, clip + SGD + EMA.
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline` (the CPU oracle - a port of the
+reference's path - timed on this box's host cores with the protocol of SURVEY 8(d) / BASELINE.md section 3).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+N_RESIDENT = 8                 # resident input batches cycled through (8 x 78.6 MB bf16 = 629 MB > the 256 MiB Infinity Cache)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--mode', choices=['infer', 'train'], default='infer')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--imgsz', type=int, default=640)
-    ap.add_argument('--inflight', type=int, default=1, help='batches in flight: S hipGraphs replayed round-robin on S streams (each step is still one full batch)')
+    ap.add_argument('--inflight', type=int, default=1, help='(experimental, refuses to print a value) S hipGraphs replayed concurrently on S streams')
     ap.add_argument('--input', choices=['model', 'f32', 'u8'], default='model',
                     help="dtype of the resident image batch: 'model' = the compute dtype, what the reference's predictor hands its model "
                          "(img.half() / 255, engine/predictor.py:128-129); 'u8' = raw uint8, /255 fused into the stem kernel")
@@ -40,200 +48,300 @@ def parse():
     ap.add_argument('--scale', default='n')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=16)
+    ap.add_argument('--resident', type=int, default=N_RESIDENT)
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, model, args):
-    """The oracle (CPU port of the reference path: forward with folded BN + NMS) on a bounded sample."""
-    from mgdt_yolo_amd.seeding import seeded_images
-    from oracle import layers as OL
-    from oracle import nms as ON
-    cores = os.cpu_count() or 1
+def launch_ranks(args):
+    """--gpus N > 1 and no launcher: start N fresh worker processes (torch.distributed.run) as a child; this parent never touches the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_cpu():
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
-    # a 1-GPU box is granted a 16-core CPU share whatever the affinity mask says: more threads only thrash
-    cores = int(os.environ.get('MGDT_CPU_THREADS', min(cores, 16)))
+        cores = os.cpu_count() or 1
+    return model, cores
+
+
+def cpu_baseline(cfg, model, args):
+    """The oracle (CPU port of the reference path, BN folded like AutoBackend(fuse=True)) timed with the protocol of SURVEY 8(d): batch 32,
+    torch threads = the host cores this process may use, 3 warm-up + >= 10 timed iterations (time.perf_counter), forward-only and
+    forward + NMS reported separately.  NMS = the reference's stages in numpy + the greedy kernel in C (the reference calls
+    torchvision's compiled kernel there)."""
+    import torch
+    from mgdt_yolo_amd.seeding import seeded_images
+    from oracle import layers as OL
+    from oracle import nms as ON
+    cpu_model, avail = host_cpu()
+    # a 1-GPU box is granted a 16-core CPU share whatever the affinity mask says: more threads only thrash (override: MGDT_CPU_THREADS)
+    cores = int(os.environ.get('MGDT_CPU_THREADS', min(avail, 16)))
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    x = seeded_images(args.cpu_images, args.imgsz, args.imgsz, seed=0)
+    b = args.batch
+    x = seeded_images(b, args.imgsz, args.imgsz, seed=0)
     strides = model.stride.tolist()
 
-    def once():
+    def fwd():
         with torch.no_grad():
-            y, _ = OL.model_forward(cfg, sd, x, strides, fused=True)
-        ON.non_max_suppression(y.numpy(), conf_thres=0.25, iou_thres=0.7)
-    once()                      # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while reps < 2 or (time.perf_counter() - t0 < 10 and reps < 20):
-        once()
+            return OL.model_forward(cfg, sd, x, strides, fused=True)[0]
+
+    def nms(y):
+        return ON.non_max_suppression(y.numpy(), conf_thres=0.25, iou_thres=0.7, compiled=True)
+
+    for _ in range(3):
+        y = fwd()
+        nms(y)
+    t_f, t_n, reps = 0.0, 0.0, 0
+    budget = float(os.environ.get('MGDT_CPU_BUDGET_S', 60))
+    while reps < 10 and (reps < 3 or t_f + t_n < budget):
+        t0 = time.perf_counter()
+        y = fwd()
+        t1 = time.perf_counter()
+        nms(y)
+        t2 = time.perf_counter()
+        t_f += t1 - t0
+        t_n += t2 - t1
         reps += 1
-    dt = time.perf_counter() - t0
-    return {'value': round(args.cpu_images * reps / dt, 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} x batch {args.cpu_images} @ {args.imgsz}x{args.imgsz}, torch-CPU fp32 oracle forward (BN folded) + numpy NMS'}
+    return {'value': round(b * reps / (t_f + t_n), 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'forward_only': round(b * reps / t_f, 2), 'forward_plus_nms': round(b * reps / (t_f + t_n), 2), 'cpu_model': cpu_model,
+            'cores_available': avail,
+            'sample': f'3 warm-up + {reps} timed x batch {b} @ {args.imgsz}x{args.imgsz}, torch-CPU fp32 oracle forward (BN folded), '
+                      f'NMS conf 0.25 / iou 0.7 (numpy stages + C greedy kernel); value = forward + NMS'}
+
+
+def roofline_of(prof_rows, reps, step_ms, graph, args):
+    """Dominant kernel family of the step from an instrumented eager pass (HIP-event pairs on the launch stream)."""
+    agg = {}
+    for name, meta, ms in prof_rows:
+        key = (name, meta['shape'] if meta else None)
+        a = agg.setdefault(key, [0.0, 0, meta])
+        a[0] += ms
+        a[1] += 1
+    total_ms = sum(v[0] for v in agg.values()) / reps
+    per_name, launches = {}, 0
+    for (name, _), v in agg.items():
+        per_name[name] = per_name.get(name, 0.0) + v[0] / reps
+        launches += v[1] // reps
+    # dominant kernel = the op with the largest share of the step; `achieved` = its algorithmic bytes (or flops) per launch / its average
+    # launch duration, both averaged over all its launches of one step (DESIGN.md section 5)
+    fam = {}
+    for (name, shape), (ms, cnt, meta) in agg.items():
+        if meta is None:
+            continue
+        f = fam.setdefault(name, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0, 'shapes': []})
+        f['ms'] += ms; f['n'] += cnt; f['flops'] += meta['flops'] * cnt; f['bytes'] += meta['bytes'] * cnt
+        f['shapes'].append((ms / reps, cnt // reps, list(shape), meta))
+    name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
+    # eager launches start on an idle queue (Python issues slower than the GPU drains), which adds a ramp to every event pair; the graph
+    # replay of the timed region has no such gaps.  Rescale the eager per-launch times so that they sum to the measured replay step.
+    scale = step_ms / total_ms if graph else 1.0
+    avg_eager_s = f['ms'] / f['n'] * 1e-3
+    avg_s = avg_eager_s * scale
+    flops_l, bytes_l = f['flops'] / f['n'], f['bytes'] / f['n']
+    ai = flops_l / bytes_l
+    ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if ai >= ridge:
+        ach = flops_l / avg_s / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                'frac': round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+    else:
+        ach = bytes_l / avg_s / 1e9
+        roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
+    kern = {'conv2d_fwd': 'conv_igemm_kernel', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
+            'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel', 'csp_block_fwd': 'csp_block_kernel'}.get(name, name)
+    traffic, tsrc, tat = None, None, None
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected
+    if os.path.exists(tfile):
+        ent = json.load(open(tfile)).get(f'{name}|{args.dtype}|b{args.batch}|{args.imgsz}')
+        if ent:
+            traffic, tsrc, tat = ent['hbm_bytes_per_launch'], ent.get('source'), ent.get('measured_at')
+    top = sorted(f['shapes'], key=lambda t: -t[0])[:6]
+    roof.update({'traffic': traffic, 'traffic_source': tsrc, 'traffic_measured_at': tat, 'kernel': f'{kern} ({name})', 'launches_per_step': f['n'] // reps,
+                 'avg_us': round(avg_s * 1e6, 2), 'avg_us_eager_events': round(avg_eager_s * 1e6, 2), 'eager_to_replay_scale': round(scale, 4),
+                 'flops_per_launch': round(flops_l), 'bytes_per_launch': round(bytes_l), 'arith_intensity': round(ai, 1),
+                 'share_of_eager_step': round(f['ms'] / reps / total_ms, 3), 'all_launches_per_step': launches,
+                 'largest_shapes_b_cin_h_w_cout_k_s': [{'shape': sh, 'launches': c, 'us_per_launch': round(ms_ / c * 1e3, 1),
+                                                        'GBps': round(m['bytes'] / (ms_ / c * 1e-3) / 1e9), 'TFLOPs': round(m['flops'] / (ms_ / c * 1e-3) / 1e12, 1)}
+                                                       for ms_, c, sh, m in top],
+                 'eager_ms_per_step_by_op': {k: round(v, 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1])},
+                 'eager_ms_per_step': round(total_ms, 3)})
+    return roof
 
 
 def main():
     args = parse()
+    if args.inflight > 1:
+        # concurrent replay of several graph instances gave wrong results on this stack (DESIGN.md section 5, tools/graph_min.py); until that is
+        # root-caused no throughput number may come out of it
+        raise SystemExit('bench.py: --inflight > 1 is disabled (concurrent hipGraph replay is not verified correct); it never feeds `value`')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
     from mgdt_yolo_amd import parallel
     rank, local, world = parallel.env_rank()
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but {world} rank(s) joined (WORLD_SIZE={world}): refusing to report a number', file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    dist = None
     if world > 1:
         dist = parallel.init('nccl', dev)
+        if dist.get_world_size() != args.gpus:
+            sys.exit(2)
 
     from mgdt_yolo_amd import ops
     from mgdt_yolo_amd.models import get_config
     from mgdt_yolo_amd.nn.tasks import DetectionModel
-    from mgdt_yolo_amd.seeding import seed_state_dict_, seeded_images
-    from mgdt_yolo_amd.yolo.utils.ops import non_max_suppression  # noqa: F401  (the user-facing form; the graph uses ops.nms)
+    from mgdt_yolo_amd.seeding import seed_state_dict_, seeded_images, seeded_labels
 
-    cfg = get_config(args.model, args.scale, 80)
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).eval().to(dev).set_compute_dtype(tdt)
-    x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100, rank)).to(dev)     # resident in HBM, values in [0, 1]
-    if args.input == 'u8':
-        x = (x * 255).round().clamp_(0, 255).to(torch.uint8)
-    elif args.input == 'model':
-        x = x.to(tdt)
+    graph_used = False
 
-    def step():
-        y, _ = model(x)
-        return ops.nms(y, 0.25, 0.7, None, False, False, 300, 30000, 7680)
+    if args.mode == 'train':
+        from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+        if args.dtype != 'f32':
+            raise SystemExit('bench.py --mode train: the training kernels compute in float32 (use --dtype f32)')
+        nc = 80
+        cfg = get_config(args.model, args.scale, nc)
+        model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).to(dev)
+        tr = DetectionTrainer(model, world_size=world)
+        R = max(1, min(args.resident, 4))
+        batches = []
+        for r in range(R):
+            lab = seeded_labels(args.batch, nc, seed=parallel.shard_seed(1000 + 17 * r, rank))
+            img = (seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100 + 17 * r, rank)) * 255).round().clamp_(0, 255).to(torch.uint8)
+            batches.append(dict(img=img.to(dev), **lab))
+        it = [0]
 
-    with torch.no_grad():
-        out = step()                       # packs the weights, allocates
-        torch.cuda.synchronize()
-        graph = None
-        if not args.no_graph:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    out = step()
-            torch.cuda.current_stream().wait_stream(side)
+        def run():
+            tr.step(batches[it[0] % R])
+            it[0] += 1
+
+        def step_eager():
+            run()
+        x_desc = 'uint8 NCHW images resident in HBM (/255 fused into the stem), synthetic labels (1-20 boxes / image)'
+        workload = (f'{args.model}-{args.scale} (nc=80) {args.imgsz}x{args.imgsz} TRAINING step, batch {args.batch}/GPU (global {world * args.batch}): '
+                    'train-mode forward (batch-stat BN) + fused assigner/loss + HIP reverse pass + bucketed RCCL all-reduce of the flat gradient buffer '
+                    '+ clip/SGD(nesterov)/EMA; BASELINE configs[2]')
+        metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, data-parallel training step'
+        parallelism = f'dp{world} (batch-sharded, one flat-gradient all-reduce per step over RCCL/xGMI)' if world > 1 else 'dp1 (no collective)'
+        n_det = None
+    else:
+        cfg = get_config(args.model, args.scale, 80)
+        model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).eval().to(dev).set_compute_dtype(tdt)
+        R = max(1, args.resident)
+        xs = []
+        for r in range(R):                                                   # resident in HBM, values in [0, 1], disjoint per rank and per slot
+            x = seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(100 + 17 * r, rank)).to(dev)
+            if args.input == 'u8':
+                x = (x * 255).round().clamp_(0, 255).to(torch.uint8)
+            elif args.input == 'model':
+                x = x.to(tdt)
+            xs.append(x)
+
+        def step(x):
+            y, _ = model(x)
+            return ops.nms(y, 0.25, 0.7, None, False, False, 300, 30000, 7680)
+
+        def step_eager():
+            return step(xs[0])
+
+        with torch.no_grad():
+            out = step(xs[0])                       # packs the weights, allocates
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-        run = graph.replay if graph is not None else step
-        if graph is not None and args.inflight > 1:
-            # S independent graph instances (own activation / NMS buffers, shared weights) on S streams: step i replays graph i % S, so the
-            # single-workgroup-per-image NMS and the small-map layers of one batch overlap the wide layers of the next
-            graphs, outs, streams = [graph], [out], [torch.cuda.Stream() for _ in range(args.inflight)]
-            for _ in range(args.inflight - 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    outs.append(step())
-                graphs.append(g)
-            counter = [0]
-
+            graphs, outs = [], []
+            if not args.no_graph:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        out = step(xs[0])
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                pool = torch.cuda.graph_pool_handle()      # the R graphs replay one after the other: they share one activation pool
+                for r in range(R):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        outs.append(step(xs[r]))
+                    graphs.append(g)
+                out = outs[-1]
+                graph_used = True
+        it = [0]
+        if graph_used:
             def run():
-                i = counter[0] % args.inflight
-                counter[0] += 1
-                streams[i].wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(streams[i]):
-                    graphs[i].replay()
+                graphs[it[0] % R].replay()
+                it[0] += 1
+        else:
+            def run():
+                nonlocal out
+                with torch.no_grad():
+                    out = step(xs[it[0] % R])
+                it[0] += 1
+        x_desc = f'{str(xs[0].dtype).replace("torch.", "")} NCHW images, {R} different batches resident in HBM ({R * xs[0].numel() * xs[0].element_size() / 2**20:.0f} MiB) cycled'
+        workload = (f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, batch {args.batch}/GPU: '
+                    f'forward + decode + NMS(conf 0.25, iou 0.7), ' + ('hipGraph replay' if graph_used else 'eager launches'))
+        metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, detection forward + NMS (whole job: {world} GPU(s))'
+        parallelism = f'replicas x{world} (batch-sharded, no data-path collective)'
 
-        for _ in range(args.warmup):
-            run()
-
-        def barrier():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        barrier()
-        elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    if args.mode == 'infer':
         n_det = int(out[2].sum().item())
-        if graph is not None and args.inflight > 1:      # every in-flight instance must have produced the same detections
-            cnt = outs[0][2]
-            valid = torch.arange(outs[0][1].shape[1], device=dev)[None, :] < cnt[:, None]        # rows past counts[b] are never written
-            for o in outs[1:]:
-                assert torch.equal(o[2], cnt) and torch.equal(o[1][valid], outs[0][1][valid]) and torch.equal(o[0][valid], outs[0][0][valid]), \
-                    'in-flight graph instances disagree'
 
-        # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
-        roof = None
-        if rank == 0:
+    # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        reps = 3
+        with torch.no_grad() if args.mode == 'infer' else torch.enable_grad():
             with ops.profile() as prof:
-                for _ in range(3):
-                    step()
-            agg = {}
-            for name, meta, ms in prof.rows:
-                key = (name, meta['shape'] if meta else None)
-                a = agg.setdefault(key, [0.0, 0, meta])
-                a[0] += ms
-                a[1] += 1
-            total_ms = sum(v[0] for v in agg.values()) / 3
-            per_name = {}
-            for (name, _), v in agg.items():
-                per_name[name] = per_name.get(name, 0.0) + v[0] / 3
-            # dominant kernel = the kernel (op) with the largest share of the step; `achieved` = its algorithmic bytes (or flops) per launch /
-            # its average launch duration, both averaged over all its launches of one step (DESIGN.md section 5)
-            fam = {}
-            for (name, shape), (ms, cnt, meta) in agg.items():
-                if meta is None:
-                    continue
-                f = fam.setdefault(name, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0, 'shapes': []})
-                f['ms'] += ms; f['n'] += cnt; f['flops'] += meta['flops'] * cnt; f['bytes'] += meta['bytes'] * cnt
-                f['shapes'].append((ms / 3, cnt // 3, list(shape), meta))
-            name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
-            # eager launches start on an idle queue (Python issues slower than the GPU drains), which adds a ramp to every event pair; the graph
-            # replay of the timed region has no such gaps.  Rescale the eager per-launch times so that they sum to the measured replay step.
-            scale = (elapsed / args.steps * 1e3) / total_ms if graph is not None else 1.0
-            avg_eager_s = f['ms'] / f['n'] * 1e-3
-            avg_s = avg_eager_s * scale
-            flops_l, bytes_l = f['flops'] / f['n'], f['bytes'] / f['n']
-            ai = flops_l / bytes_l
-            ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
-            if ai >= ridge:
-                ach = flops_l / avg_s / 1e12
-                roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
-                        'frac': round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4)}
-            else:
-                ach = bytes_l / avg_s / 1e9
-                roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-            kern = {'conv2d_fwd': 'conv_igemm_kernel', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
-                    'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel'}.get(name, name)
-            traffic, tsrc = None, None
-            tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected
-            if os.path.exists(tfile):
-                ent = json.load(open(tfile)).get(f'{name}|{args.dtype}|b{args.batch}|{args.imgsz}')
-                if ent:
-                    traffic, tsrc = ent['hbm_bytes_per_launch'], ent.get('source')
-            top = sorted(f['shapes'], key=lambda t: -t[0])[:6]
-            roof.update({'traffic': traffic, 'traffic_source': tsrc, 'kernel': f'{kern} ({name})', 'launches_per_step': f['n'] // 3,
-                         'avg_us': round(avg_s * 1e6, 2), 'avg_us_eager_events': round(avg_eager_s * 1e6, 2), 'eager_to_replay_scale': round(scale, 4), 'flops_per_launch': round(flops_l), 'bytes_per_launch': round(bytes_l), 'arith_intensity': round(ai, 1),
-                         'share_of_eager_step': round(f['ms'] / 3 / total_ms, 3),
-                         'largest_shapes_b_cin_h_w_cout_k_s': [{'shape': sh, 'launches': c, 'us_per_launch': round(ms_ / c * 1e3, 1),
-                                                                'GBps': round(m['bytes'] / (ms_ / c * 1e-3) / 1e9), 'TFLOPs': round(m['flops'] / (ms_ / c * 1e-3) / 1e12, 1)}
-                                                               for ms_, c, sh, m in top],
-                         'eager_ms_per_step_by_op': {k: round(v, 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1])},
-                         'eager_ms_per_step': round(total_ms, 3)})
+                for _ in range(reps):
+                    step_eager()
+        roof = roofline_of(prof.rows, reps, elapsed / args.steps * 1e3, graph_used, args)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = parallel.aggregate_throughput(args.batch, args.steps, elapsed, world)
-        line = {'metric': 'images/sec @640x640 bs=32 per GPU, detection forward + NMS', 'value': round(value, 1), 'unit': 'images/sec',
+        line = {'metric': metric, 'value': round(value, 1), 'unit': 'images/sec',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-                'config': {'workload': f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, '
-                                       f'batch {args.batch}/GPU: forward + decode + NMS(conf 0.25, iou 0.7), hipGraph replay' + (f', {args.inflight} batches in flight' if args.inflight > 1 else '') if graph is not None
-                           else f'{args.model}-{args.scale} {args.imgsz}x{args.imgsz} eager',
-                           'global_batch': world * args.batch, 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
-                           'input': f'{str(x.dtype).replace("torch.", "")} NCHW images resident in HBM', 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)'},
+                'config': {'workload': workload, 'global_batch': world * args.batch, 'parallelism': parallelism, 'rccl_ranks': world,
+                           'input': x_desc, 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)',
+                           'timed_region_s': round(elapsed, 3)},
                 'roofline': roof}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.mode == 'infer':
             line['cpu_baseline'] = cpu_baseline(cfg, model, args)
         else:
             line['cpu_baseline'] = None

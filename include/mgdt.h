@@ -251,11 +251,12 @@ int mgdt_grn_bwd(const mgdt_view* g, const mgdt_view* t, const float* S, const f
 
 /* ---- optimizer step on the flat parameter buffer (yolo/engine/trainer.py:462-470,633-664; torch_utils.py:335-367) ----------
  * clip: out2 = {total grad norm, min(1, max_norm/(norm+1e-6))} on device (no host sync); sgd: torch.optim.SGD(nesterov) with a
- * per-element weight-decay vector (0 for BN weights and biases) and the clip coefficient read from device memory.            */
+ * per-element weight-decay vector (0 for norm weights; a negative entry marks the bias group of trainer.py:644: no decay, stepped
+ * with `lr_bias`, the warm-up bias learning rate of trainer.py:323) and the clip coefficient read from device memory.        */
 size_t mgdt_grad_norm_workspace_bytes(void);
 int mgdt_grad_clip_coef(const float* g, long n, float max_norm, float* out2, void* ws, mgdt_stream s);
-int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float momentum, int nesterov, int first,
-                  const float* clip2, mgdt_stream s);
+int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float lr_bias, float momentum, int nesterov,
+                  int first, const float* clip2, mgdt_stream s);
 int mgdt_ema_update(float* ema, const float* p, long n, float decay, mgdt_stream s);
 
 #ifdef __cplusplus

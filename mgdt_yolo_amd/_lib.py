@@ -88,7 +88,7 @@ PROTOTYPES = {
     'mgdt_grn_bwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_grad_norm_workspace_bytes': (_sz, []),
     'mgdt_grad_clip_coef': (_i, [_vp, C.c_long, _f, _vp, _vp, _vp]),
-    'mgdt_sgd_step': (_i, [_vp, _vp, _vp, _vp, C.c_long, _f, _f, _i, _i, _vp, _vp]),
+    'mgdt_sgd_step': (_i, [_vp, _vp, _vp, _vp, C.c_long, _f, _f, _f, _i, _i, _vp, _vp]),
     'mgdt_ema_update': (_i, [_vp, _vp, C.c_long, _f, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

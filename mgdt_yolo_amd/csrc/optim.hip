@@ -37,21 +37,23 @@ extern "C" int mgdt_grad_clip_coef(const float* g, long n, float max_norm, float
 }
 
 // g' = clip*g + wd[i]*p ; buf = first ? g' : momentum*buf + g' ; step = nesterov ? g' + momentum*buf : buf ; p -= lr*step
+// wd[i] < 0 marks the reference's bias group (trainer.py:644): no decay and its own learning rate `lr_bias` (warm-up, trainer.py:323)
 __global__ void sgd_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, const float* __restrict__ wd, long n,
-                                float lr, float momentum, int nesterov, int first, const float* __restrict__ clip) {
+                                float lr, float lr_bias, float momentum, int nesterov, int first, const float* __restrict__ clip) {
   const float c = clip ? clip[1] : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float gi = c * g[i] + (wd ? wd[i] * p[i] : 0.f);
+    const float w = wd ? wd[i] : 0.f;
+    float gi = c * g[i] + (w > 0.f ? w * p[i] : 0.f);
     float b = first ? gi : momentum * buf[i] + gi;
     buf[i] = b;
-    p[i] -= lr * (nesterov ? gi + momentum * b : b);
+    p[i] -= (w < 0.f ? lr_bias : lr) * (nesterov ? gi + momentum * b : b);
   }
 }
-extern "C" int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float momentum, int nesterov, int first,
-                             const float* clip2, mgdt_stream s) {
+extern "C" int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float lr_bias, float momentum, int nesterov,
+                             int first, const float* clip2, mgdt_stream s) {
   if (!p || !g || !buf || n <= 0) MGDT_FAIL(MGDT_BAD_ARG, "sgd_step: null/empty argument");
   int nb = (int)std::min<long>((n + 255) / 256, 8192);
-  sgd_flat_kernel<<<nb, 256, 0, (hipStream_t)s>>>(p, g, buf, wd, n, lr, momentum, nesterov, first, clip2);
+  sgd_flat_kernel<<<nb, 256, 0, (hipStream_t)s>>>(p, g, buf, wd, n, lr, lr_bias, momentum, nesterov, first, clip2);
   MGDT_CHECK_LAUNCH("sgd_step");
   return MGDT_OK;
 }

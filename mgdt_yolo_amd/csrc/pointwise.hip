@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <vector>
 
+#include <type_traits>
 #include "common.h"
 
 #define SPR_SPLITS 16
@@ -79,7 +80,10 @@ __global__ void copy_kernel(const TX* __restrict__ x, long xsn, long xsh, long x
     t /= W;
     int h = (int)(t % H);
     int n = (int)(t / H);
-    y[n * ysn + h * ysh + w * ysw + c * ysc] = (TY)(float)x[n * xsn + h * xsh + w * xsw + c * xsc];
+    float v;
+    if constexpr (std::is_same<TX, uint8_t>::value) v = (float)x[n * xsn + h * xsh + w * xsw + c * xsc] / 255.0f;   // the preprocess division, exact
+    else v = (float)x[n * xsn + h * xsh + w * xsw + c * xsc];
+    y[n * ysn + h * ysh + w * ysw + c * ysc] = (TY)v;
   }
 }
 
@@ -100,7 +104,7 @@ extern "C" int mgdt_copy_fwd(const mgdt_view* x, int xdt, const mgdt_view* y, in
   if (x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "copy: shape mismatch");
   long total = (long)x->n * x->h * x->w * x->c;
   hipStream_t st = (hipStream_t)s;
-  if (total < 0x7fffffffL && vecN_ok(x, xdt, 8) && vecN_ok(y, ydt, 8)) {   // NHWC both sides: 8 channels per lane
+  if (total < 0x7fffffffL && xdt != MGDT_U8 && vecN_ok(x, xdt, 8) && vecN_ok(y, ydt, 8)) {   // NHWC both sides: 8 channels per lane
     PixIdx d = make_pixidx(x->h, x->w, x->c / 8);
     uint32_t tv = (uint32_t)(total / 8);
     int g = grid_for(tv);
@@ -120,6 +124,8 @@ extern "C" int mgdt_copy_fwd(const mgdt_view* x, int xdt, const mgdt_view* y, in
   else if (xdt == MGDT_F32 && ydt == MGDT_BF16) L(float, bf16);
   else if (xdt == MGDT_BF16 && ydt == MGDT_F32) L(bf16, float);
   else if (xdt == MGDT_BF16 && ydt == MGDT_BF16) L(bf16, bf16);
+  else if (xdt == MGDT_U8 && ydt == MGDT_F32) L(uint8_t, float);       // uint8 image / 255 (detect/train.py:64) into a float map
+  else if (xdt == MGDT_U8 && ydt == MGDT_BF16) L(uint8_t, bf16);
   else MGDT_FAIL(MGDT_BAD_DTYPE, "copy: dtypes %d -> %d", xdt, ydt);
 #undef L
   MGDT_CHECK_LAUNCH("copy_fwd");

@@ -135,7 +135,7 @@ class MSPA_C2f(HipModule):
         at = self.attention
         if train:
             attn, part = ops.spr_attention_train(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
-            self.__dict__.setdefault('_ctx', []).append((out, attn, part, x.shape))
+            self._save_ctx((out, attn, part, x.shape))
         else:
             return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)   # pool, then MLP + scaling in one launch
         return ops.scale_channels(out, attn)
@@ -200,7 +200,7 @@ class SPPF(HipModule):
         (self.cv1.train_fwd if train else self.cv1.run)(x, out=cat[:, :c_])
         ops.sppf_pools(cat[:, :c_], cat[:, c_:2 * c_], cat[:, 2 * c_:3 * c_], cat[:, 3 * c_:])
         if train:
-            self._cat = cat
+            self._cat = cat if ops.ctx_enabled() else None
         return (self.cv2.train_fwd if train else self.cv2.run)(cat)
 
     def backward(self, g):
@@ -375,7 +375,7 @@ class InjectionMultiSum_Auto_pool(HipModule):
             return ops.conv1x1_inject(x_l, le.packed(dt, direct=False), ga, gf)   # local map never leaves the chip
         local = f(le)(x_l)
         if train:
-            self.__dict__.setdefault('_ctx', []).append((local, ga, x_g.shape, c0))
+            self._save_ctx((local, ga, x_g.shape, c0))
         return ops.inject(local, ga, gf)                    # pool vs up-sample branch chosen from the shapes (block.py:369)
 
     def backward(self, g):

@@ -54,8 +54,16 @@ class HipModule(nn.Module):
     @staticmethod
     def _no_train_bn(m):
         if m.training:
-            raise NotImplementedError('training-mode BatchNorm (batch statistics) + backward kernels are not built in this round; '
-                                      'call .eval() (raw head maps for the loss: model.model[-1].training = True)')
+            raise NotImplementedError('this call path folds BatchNorm running statistics into the weights (eval); the training-mode path '
+                                      '(batch statistics + backward) is Conv.train_fwd / Conv.backward - call the module in .train() mode '
+                                      'through forward(), or .eval() it (raw head maps for the loss: model.model[-1].training = True)')
+
+    def _save_ctx(self, item):
+        """Keep what backward() needs.  Nothing is kept when no backward can follow (torch.no_grad() outside the model-level autograd
+        Function), and DetectionModel._predict_once drops every stale context at the start of a train-mode forward, so a forward that is
+        never followed by a backward cannot pin activations."""
+        if ops.ctx_enabled():
+            self.__dict__.setdefault('_ctx', []).append(item)
 
 
 class Conv(HipModule):
@@ -108,6 +116,9 @@ class Conv(HipModule):
         dt = self.out_dtype(x) if out is None else out.dtype
         if dt != torch.float32:
             raise NotImplementedError('training runs in float32 in this round (bf16 training kernels: next)')
+        if self.conv.groups != 1:
+            raise NotImplementedError('grouped / depth-wise Conv has no training kernels (weight and data gradients assume groups == 1); '
+                                      'DWConv is not instantiated by any target YAML')
         mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
         pk = self._cached(('raw', dt, not mfma), [self.conv.weight],
                           lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma, groups=self.conv.groups))
@@ -117,12 +128,14 @@ class Conv(HipModule):
         bn = self.bn
         mean, rstd = ops.bn_stats(y, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         z = ops.bn_act(y, mean, rstd, bn.weight, bn.bias, act_code(self.act), out=out, r1=r1, r2=r2)
-        self.__dict__.setdefault('_ctx', []).append((x, x2, y, mean, rstd, k, s))
+        self._save_ctx((x, x2, y, mean, rstd, k, s))
         return z
 
     def backward(self, gz, need_dx=True, dx_out=None):
         """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx
         (written into the view `dx_out` when given)."""
+        if self.conv.groups != 1:
+            raise NotImplementedError('grouped / depth-wise Conv has no backward kernels')
         x, x2, y, mean, rstd, k, s = self._ctx.pop()
         bn = self.bn
         ops.grad_buf(bn.weight)

@@ -65,7 +65,7 @@ class ConvNeXtV2_Block(HipModule):
         scale = ops.grn_scale(t2, gb[0])
         t3 = ops.channel_affine(t2, scale, gb[1])
         out = ops.conv2d(t3, pw2, 1, ops.ACT_NONE, r1=x)
-        self.__dict__.setdefault('_ctx', []).append((x, u, t1, y1, t2, t3, S, pw1_raw, pw2, dw, gb))
+        self._save_ctx((x, u, t1, y1, t2, t3, S, pw1_raw, pw2, dw, gb))
         return out
 
     def forward(self, x):

@@ -76,7 +76,7 @@ class Detect(HipModule):
             _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
             _HeadConv.run(self, self.cv3[i][2], tc, feat[:, r4:])
             if self.training:
-                self.__dict__.setdefault('_ctx', []).append((tb, tc))
+                self._save_ctx((tb, tc))
             x[i] = feat
         if self.training:
             return x

@@ -26,6 +26,34 @@ REGISTRY = {c.__name__: c for c in (Conv, DWConv, Concat, Bottleneck, C2f, MSPA_
 REGISTRY['nn.Upsample'] = Upsample
 
 
+class _TrainForwardFn(torch.autograd.Function):
+    """Makes the explicit HIP reverse pass reachable from `loss.backward()` - the reference's training call sequence
+    `self.loss, self.loss_items = self.model(batch)` -> `self.scaler.scale(self.loss).backward()` (yolo/engine/trainer.py:334-343).
+
+    forward: the train-mode layer loop (`_predict_once`) with every module keeping its backward context; the raw head maps come out as
+    autograd outputs.  backward: `BaseModel.backward(head_grads)` launches the adjoint kernels and writes each parameter's `.grad`
+    directly (into the trainer's flat gradient buffer when there is one), so nothing is returned to autograd for the parameters - the
+    anchor input only exists to make autograd call us.  Gradient w.r.t. the image is not produced (the reference never asks for it)."""
+
+    @staticmethod
+    def forward(ctx, model, x, anchor):
+        with ops.force_ctx():
+            feats = model._predict_once(x)
+        ctx.model = model
+        ctx.n = len(feats)
+        return tuple(feats)
+
+    @staticmethod
+    def backward(ctx, *gfeats):
+        model = ctx.model
+        gfeats = [g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last) for g in gfeats]
+        acc = model._accumulate_snapshot() if getattr(model, 'grad_accumulate', False) else None
+        model.backward(gfeats)
+        if acc is not None:
+            model._accumulate_restore(acc)
+        return None, None, None
+
+
 class BaseModel(nn.Module):
     """Reference: nn/tasks.py BaseModel (:28-216)."""
 
@@ -37,12 +65,20 @@ class BaseModel(nn.Module):
     def predict(self, x, profile=False, visualize=False, augment=False):
         if augment or profile or visualize:
             raise RuntimeError('augment / profile / visualize are host-side tooling outside the hot path')
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.model[0].parameters()):
+            # training call form of the reference: the outputs carry a grad_fn, `loss.backward()` runs the HIP reverse pass
+            if not hasattr(self, '_anchor'):
+                self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+            return list(_TrainForwardFn.apply(self, x, self._anchor))
         return self._predict_once(x)
 
     def _predict_once(self, x, profile=False, visualize=False):
         """Per-layer dispatch with the save-list (tasks.py:65-87)."""
         if not x.is_cuda:
             raise RuntimeError('mgdt_yolo_amd runs on MI355X (HIP) only: move the model and the input to cuda (no CPU fallback)')
+        if self.training:       # contexts of a forward that was never followed by a backward (validation under train(), an aborted step) go now
+            for m in self.modules():
+                m.__dict__.pop('_ctx', None)
         y = []
         for m in self.model:
             if m.f != -1:
@@ -51,16 +87,19 @@ class BaseModel(nn.Module):
             y.append(x if m.i in self.save else None)
         return x
 
-    def backward(self, head_grads):
+    def backward(self, head_grads, layer_done=None):
         """Explicit reverse pass over the layer list (the counterpart of `_predict_once`; replaces torch.autograd on the
         hot path): `head_grads` = d loss / d raw head maps (list, one per level).  Every module's `backward` launches its HIP
         adjoint kernels and fills `.grad` of its parameters (overwrite semantics); gradients of tensors with several
-        consumers (the save-list) are summed with the HIP add kernel."""
+        consumers (the save-list) are summed with the HIP add kernel.  `layer_done(i)` is called after layer i's kernels are queued (the
+        trainer hangs its bucketed gradient all-reduce on it)."""
         n = len(self.model)
         pend = {n - 1: head_grads}
         for m in reversed(list(self.model)):
             g = pend.pop(m.i, None)
             if g is None:
+                if layer_done is not None:
+                    layer_done(m.i)
                 continue
             if not hasattr(m, 'backward'):
                 raise NotImplementedError(f'{type(m).__name__}.backward is not built yet (training path of this module: next)')
@@ -79,6 +118,22 @@ class BaseModel(nn.Module):
                     pend[j] = ops.add(pend[j], gi, out=dst) if dst is not None else ops.add(pend[j], gi)
                 else:
                     pend[j] = gi
+            if layer_done is not None:
+                layer_done(m.i)
+
+    # gradient accumulation over micro-batches (trainer.py:250,345): the adjoint kernels overwrite `.grad`, so the running sum is kept aside
+    def _accumulate_snapshot(self):
+        fs = getattr(self, '_flat_state', None)
+        if fs is not None:                                  # the trainer's flat gradient buffer: one copy
+            return fs.grad.clone()
+        return [(p, p.grad.clone()) for p in self.parameters() if p.requires_grad and p.grad is not None]
+
+    def _accumulate_restore(self, snap):
+        if torch.is_tensor(snap):
+            self._flat_state.grad.add_(snap)
+            return
+        for p, g in snap:
+            p.grad.add_(g)
 
     def fuse(self, verbose=True):
         """Fold BatchNorm into the conv parameters and drop the bn modules (tasks.py:121-146)."""

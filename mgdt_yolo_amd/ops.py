@@ -66,6 +66,24 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_FORCE_CTX = [0]
+
+
+def ctx_enabled():
+    """True when a train-mode forward should keep activations for backward(): autograd is recording, or the model-level
+    autograd Function (which runs its forward under no_grad) asked for it."""
+    return _FORCE_CTX[0] > 0 or torch.is_grad_enabled()
+
+
+class force_ctx:
+    def __enter__(self):
+        _FORCE_CTX[0] += 1
+
+    def __exit__(self, *exc):
+        _FORCE_CTX[0] -= 1
+        return False
+
+
 def view(t):
     """(B,C,H,W) tensor of any strides -> mgdt_view (NHWC-ordered sizes/strides)."""
     _need_gpu(t)
@@ -223,7 +241,7 @@ def nearest(x, out):
 
 def copy(x, out):
     """Strided copy with cast (channel concat, NCHW<->NHWC, fp32<->bf16)."""
-    _launch('copy_fwd', 'mgdt_copy_fwd', vp(x), dtype_code(x.dtype), vp(out), dtype_code(out.dtype), stream())
+    _launch('copy_fwd', 'mgdt_copy_fwd', vp(x), U8 if x.dtype == torch.uint8 else dtype_code(x.dtype), vp(out), dtype_code(out.dtype), stream())
     return out
 
 
@@ -548,11 +566,11 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
 
 def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
     lib = L.lib()
-    if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype == torch.float32 and x2 is None and not accumulate and x.shape[1] < 4:
+    if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype in (torch.float32, torch.uint8) and x2 is None and not accumulate and x.shape[1] < 4:
         # the 3-channel image (NCHW): one strided copy into a 4-channel NHWC buffer (4th channel zero) puts the stem on the tiled NHWC kernel;
         # the generic kernel would scan every pixel once per weight element
         b, c, h, w = x.shape
-        x4 = new_act(b, 4, h, w, x.dtype, x.device).zero_()
+        x4 = new_act(b, 4, h, w, torch.float32, x.device).zero_()      # a uint8 image is divided by 255 by the copy (detect/train.py:64)
         copy(x, x4[:, :c])
         dw4 = torch.empty((dw.shape[0], 4, k, k), dtype=torch.float32, device=x.device)
         conv_wgrad(x4, dy, k, stride, dw4, dbias=dbias)
@@ -678,9 +696,10 @@ def grad_clip_coef(flat_grad, max_norm):
 PARAM_EPOCH = [0]
 
 
-def sgd_step(p, g, buf, wd, lr, momentum, nesterov, first, clip=None):
+def sgd_step(p, g, buf, wd, lr, momentum, nesterov, first, clip=None, lr_bias=None):
     PARAM_EPOCH[0] += 1
-    _launch('sgd_step', 'mgdt_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), float(lr), float(momentum), int(nesterov), int(first), ptr(clip), stream())
+    _launch('sgd_step', 'mgdt_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), float(lr), float(lr if lr_bias is None else lr_bias), float(momentum),
+            int(nesterov), int(first), ptr(clip), stream())
 
 
 def ema_update(ema, p, decay):

@@ -18,6 +18,19 @@ def init(backend, device=None):
     return dist
 
 
+def world():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def broadcast_(flat, src=0):
+    """Initial parameter / buffer broadcast of data-parallel training (what DDP's constructor does, trainer.py:225): one message."""
+    import torch.distributed as dist
+    if world() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
 def shard_seed(base, rank):
     """Each replica gets a disjoint synthetic batch."""
     return base + rank

@@ -45,6 +45,30 @@ def greedy_nms(boxes, iou_thres):
     return np.asarray(keep, np.int64)
 
 
+_CLIB = None
+
+
+def greedy_nms_c(boxes, iou_thres, limit=0):
+    """oracle/csrc/greedy_nms.c through ctypes: the same arithmetic as `greedy_nms` in compiled code (what the reference's CPU path has
+    at this call: torchvision's C++ kernel).  `limit` > 0 stops after that many keepers (a prefix of the full answer).  Used by the
+    timed CPU baseline; checked equal to `greedy_nms` in tests/test_oracle_golden.py."""
+    global _CLIB
+    import ctypes as C
+    import os
+    if _CLIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_build', 'liboracle.so')
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} is missing: run `make -C oracle` (or __graft_entry__.build())')
+        _CLIB = C.CDLL(path)
+        _CLIB.oracle_greedy_nms.restype = C.c_int64
+        _CLIB.oracle_greedy_nms.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int64, C.c_void_p]
+    b = np.ascontiguousarray(boxes, F32)
+    keep = np.empty(max(len(b), 1), np.int64)
+    n = _CLIB.oracle_greedy_nms(b.ctypes.data, len(b), float(F32(iou_thres)), int(limit), keep.ctypes.data)
+    assert n >= 0
+    return keep[:n].copy()
+
+
 def nms_candidates(pred_img, conf_thres, multi_label, classes=None, nc=None):
     """Stages ops.py:201-238 for one image.  pred_img: (4+nc, A) float32.
 
@@ -75,7 +99,7 @@ def nms_candidates(pred_img, conf_thres, multi_label, classes=None, nc=None):
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                        multi_label=False, max_det=300, nc=0, max_nms=30000, max_wh=7680, return_index=False):
+                        multi_label=False, max_det=300, nc=0, max_nms=30000, max_wh=7680, return_index=False, compiled=False):
     """yolo/utils/ops.py:136-266. prediction (B, 4+nc, A) -> list of (n_i, 6) float32 arrays.
 
     With return_index=True also returns, per image, (anchor index, class) int64 arrays of the kept rows.
@@ -92,7 +116,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         order = np.argsort(-conf, kind='stable')[:max_nms]          # ops.py:244 (+ tie rule)
         b, conf, cls, anc = b[order], conf[order], cls[order], anc[order]
         c = cls.astype(F32) * F32(0 if agnostic else max_wh)         # ops.py:247
-        keep = greedy_nms((b + c[:, None]).astype(F32), iou_thres)[:max_det]   # ops.py:248-250
+        shifted = (b + c[:, None]).astype(F32)
+        keep = (greedy_nms_c(shifted, iou_thres, max_det) if compiled else greedy_nms(shifted, iou_thres))[:max_det]   # ops.py:248-250
         out.append(np.concatenate([b[keep], conf[keep, None], cls[keep, None].astype(F32)], 1).astype(F32))
         kept.append((anc[keep], cls[keep]))
     return (out, kept) if return_index else out

@@ -205,8 +205,33 @@ def val_match():
     save('val_match', **arrs)
 
 
+# ------------------------------------------------------------------ optimizer parameter groups (yolo/engine/trainer.py:615-664)
+def optim_groups():
+    """Runs the reference's BaseTrainer.build_optimizer on the reference's own model and records which group every parameter lands in.
+    The method is taken out of the class with `ast` (importing engine/trainer.py needs the whole data / logging stack) and executed as is."""
+    import ast
+    from torch import nn, optim
+    src = open('/root/reference/yolo/engine/trainer.py').read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == 'BaseTrainer')
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'build_optimizer')
+    env = {'nn': nn, 'optim': optim, 'LOGGER': types.SimpleNamespace(info=lambda *a, **k: None), 'colorstr': lambda *a: ''}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'ref:build_optimizer', 'exec'), env)
+    arrs = {}
+    for tag, yname in E2E_MODELS.items():
+        m = build(yname + '.yaml')
+        me = types.SimpleNamespace(args=types.SimpleNamespace(warmup_bias_lr=0.1))
+        opt = env['build_optimizer'](me, m, name='SGD', lr=0.001, momentum=0.937, decay=5e-4, iterations=1e5)
+        ident = {id(p): n for n, p in m.named_parameters()}
+        # param_groups order of the reference: [0] biases, [1] decayed weights, [2] norm weights
+        for gi, key in enumerate(('bias', 'decay', 'norm')):
+            arrs[f'{tag}_{key}'] = '\n'.join(ident[id(p)] for p in opt.param_groups[gi]['params'])
+            assert opt.param_groups[gi]['weight_decay'] == (5e-4 if key == 'decay' else 0.0)
+        print('optim_groups', tag, [len(g['params']) for g in opt.param_groups])
+    save('optim_groups', **arrs)
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match']
+    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match', 'optim_groups']
     models = {}
     if 'e2e' in what or 'nms' in what:
         for tag, yname in E2E_MODELS.items():
@@ -223,3 +248,5 @@ if __name__ == '__main__':
         nms(models)
     if 'val_match' in what:
         val_match()
+    if 'optim_groups' in what:
+        optim_groups()

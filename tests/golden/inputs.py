@@ -11,6 +11,8 @@ MODULE_CASES = {
     'conv1': ('Conv', (40, 8, 1, 1), [(2, 40, 9, 7)]),
     'conv1_noact': ('Conv', (16, 32, 1, 1, None, 1, 1, False), [(1, 16, 8, 8)]),
     'conv1_relu': ('Conv', (16, 32, 1, 1, None, 1, 1, 'relu'), [(1, 16, 8, 8)]),
+    'dwconv3': ('DWConv', (16, 32, 3, 1), [(2, 16, 13, 11)]),          # groups = gcd(16, 32) = 16: two outputs per input channel
+    'dwconv5s2': ('DWConv', (24, 24, 5, 2), [(2, 24, 12, 9)]),         # true depth-wise, k5 stride 2
     'bottleneck_add': ('Bottleneck', (16, 16, True, 1, ((3, 3), (3, 3)), 1.0), [(2, 16, 12, 10)]),
     'c2f': ('C2f', (48, 32, 2, False), [(2, 48, 12, 10)]),
     'c2f_sc': ('C2f', (32, 32, 1, True), [(2, 32, 12, 10)]),

@@ -239,6 +239,60 @@ def test_tood_model_e2e_fp32_matches_oracle():
     np.testing.assert_allclose(y.cpu().numpy()[:, 4:], y_ref.numpy()[:, 4:], atol=1e-3)
 
 
+@pytest.mark.parametrize('hw', [(160, 160), (320, 192)])
+def test_tood_scale_s_model_fp32_matches_oracle(hw):
+    """BASELINE configs[3] model (MSPA-C2f + GD + TOODHead, scale s, hidc 128) vs oracle.layers.model_forward (TOOD part unpinned: mmcv absent)."""
+    from oracle import layers as OL
+    name = 'mspa_c2f_gd_tood_yolov8_hidc128'
+    cfg = get_config(name, 's', 80)
+    m = build_model(name, scale='s')
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x = seeded_images(1, *hw, seed=5)
+    with torch.no_grad():
+        y_ref, feats_ref = OL.model_forward(cfg, sd, x, [8.0])
+        y, feats = m(x.to(DEV))
+    np.testing.assert_allclose(to_nchw(feats[0]), feats_ref[0].numpy(), atol=5e-3, rtol=5e-3)
+    np.testing.assert_allclose(y.cpu().numpy()[:, 4:], y_ref.numpy()[:, 4:], atol=1e-3)
+    np.testing.assert_allclose(y.cpu().numpy()[:, :4], y_ref.numpy()[:, :4], atol=5e-2)       # boxes in px, reg_max 16 at stride 8
+
+
+def test_tood_scale_s_at_1280_properties():
+    """BASELINE configs[3] at its full size (1x3x1280x1280, 25 600 anchors): too large for the CPU oracle to be a per-test checker, so
+    size-independent properties: finite outputs, fp32 vs bf16 within the stated bf16 bound, boxes inside a sane range, NMS idempotent."""
+    from mgdt_yolo_amd.yolo.utils.ops import nms_with_index
+    name = 'mspa_c2f_gd_tood_yolov8_hidc128'
+    x = seeded_images(1, 1280, 1280, seed=9).to(DEV)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = build_model(name, dt, scale='s')
+        with torch.no_grad():
+            y, feats = m(x.to(dt))
+        assert y.shape == (1, 84, 160 * 160) and feats[0].shape == (1, 64 + 80, 160, 160)
+        assert torch.isfinite(y).all()
+        outs[dt] = y.float()
+    y32, y16 = outs[torch.float32], outs[torch.bfloat16]
+    eb = (y32[:, :4] - y16[:, :4]).abs()
+    ec = (y32[:, 4:] - y16[:, 4:]).abs()
+    print(f'tood-s 1280: bf16 vs fp32 box max {eb.max().item():.3f} px mean {eb.mean().item():.4f}; conf max {ec.max().item():.4f}')
+    assert ec.max().item() < 0.1 and eb.mean().item() < 0.5 and eb.max().item() < 8.0        # reg_max 16: one bin = 8 px at stride 8
+    assert (y32[:, 2:4] > 0).all() and y32[:, :2].min().item() > -200 and y32[:, :2].max().item() < 1480
+    rows, kept = nms_with_index(y32, conf_thres=0.25, iou_thres=0.7)
+    assert len(kept[0]) > 0
+    # idempotence: NMS over the kept boxes alone keeps every one of them
+    sub = y32[:, :, kept[0].long()].contiguous()
+    rows2, kept2 = nms_with_index(sub, conf_thres=0.25, iou_thres=0.7)
+    assert len(kept2[0]) == len(kept[0]) and torch.equal(rows2[0], rows[0])
+
+
+def test_dwconv_has_no_training_kernels_and_says_so():
+    """Grouped convs are inference-only (weight / data gradient kernels assume groups == 1): train mode must refuse, not corrupt memory."""
+    from mgdt_yolo_amd.nn.modules import DWConv
+    m = seed_state_dict_(DWConv(16, 32, 3, 1), 1).to(DEV).train()
+    x = torch.randn(2, 16, 9, 9, device=DEV).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(NotImplementedError, match='grouped'):
+        m(x)
+
+
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
 CONV_CASES = [  # cin, cout, k, s, h, w  (+ channel-sliced / fused variants below)
     (8, 8, 1, 1, 20, 24), (8, 8, 3, 1, 17, 13), (16, 32, 3, 2, 33, 29), (32, 64, 3, 2, 20, 20), (64, 128, 3, 2, 12, 12),
@@ -359,7 +413,29 @@ def test_e2e_bf16_stated_tolerance(golden, tag):
     y = y.cpu().numpy()
     eb, ec = np.abs(y[:, :4] - ref[:, :4]).max(), np.abs(y[:, 4:] - ref[:, 4:]).max()
     print(f'bf16 {tag}: max box err {eb:.4f} px, max conf err {ec:.4f}')
-    assert eb < 1.5 and ec < 0.05, (eb, ec)
+    assert eb < BF16_TOL[tag][0] and ec < BF16_TOL[tag][1], (eb, ec)
+
+
+# bf16 throughput path vs the fp32 REFERENCE: stated tolerances = ~2x the errors measured on MI355X (printed by the tests; round 2:
+# see DESIGN.md section 4).  (max box error in px, max confidence error) over every anchor / class of the compared outputs.
+BF16_TOL = {'mspa_c2f_gd_n': (1.5, 0.05), 'yolov8_n': (1.5, 0.05)}
+BF16_TOL_640 = {'mspa_c2f_gd_n': (1.5, 0.05), 'yolov8_n': (1.5, 0.05)}
+
+
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_e2e_bf16_at_headline_size_vs_reference(golden, tag):
+    """The headline dtype at the headline size: bf16 forward of 1x640x640 against the reference's fp32 output (fixture ysub_1x640x640,
+    every 25th anchor of 6400 / 8400, all 84 rows)."""
+    g = golden('e2e_' + tag)
+    m = build_model(GI.E2E_MODELS[tag], torch.bfloat16)
+    x = seeded_images(1, 640, 640, seed=GI.IMG_SEED).to(DEV)
+    with torch.no_grad():
+        y, _ = m(x.to(torch.bfloat16))
+    ref = g['ysub_1x640x640']
+    y = y.cpu().numpy()[:, :, ::25]
+    eb, ec = np.abs(y[:, :4] - ref[:, :4]).max(), np.abs(y[:, 4:] - ref[:, 4:]).max()
+    print(f'bf16 640 {tag}: max box err {eb:.4f} px, max conf err {ec:.4f}; mean box err {np.abs(y[:, :4] - ref[:, :4]).mean():.4f}')
+    assert eb < BF16_TOL_640[tag][0] and ec < BF16_TOL_640[tag][1], (eb, ec)
 
 
 def test_cpu_tensor_is_refused():
@@ -607,8 +683,11 @@ def test_optimizer_step_matches_torch_sgd_and_loss_decreases():
     for k, p in ref.items():
         p.grad = grads[k].clone()
     torch.nn.utils.clip_grad_norm_(list(ref.values()), 10.0)
-    decay = [p for k, p in ref.items() if k.endswith('.weight') and p.ndim > 1]
-    nodecay = [p for k, p in ref.items() if not (k.endswith('.weight') and p.ndim > 1)]
+    from mgdt_yolo_amd.yolo.engine.trainer import param_groups
+    grp = param_groups(m)                      # the reference's build_optimizer rule (pinned by tests/golden/optim_groups.npz on the CPU side)
+    decay = [p for k, p in ref.items() if grp[k] == 0]
+    nodecay = [p for k, p in ref.items() if grp[k] != 0]
+    assert any('grn.gamma' in k and grp[k] == 0 for k in ref) and any(k.endswith('norm.weight') and grp[k] == 0 for k in ref)
     opt = torch.optim.SGD([{'params': decay, 'weight_decay': 5e-4}, {'params': nodecay, 'weight_decay': 0.0}], lr=0.01, momentum=0.937, nesterov=True)
     opt.step()
     for k, p in trainable:
@@ -616,7 +695,83 @@ def test_optimizer_step_matches_torch_sgd_and_loss_decreases():
     losses = [l0.item()] + [tr.step(batch)[0].item() for _ in range(8)]
     print('losses', [round(v, 2) for v in losses])
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
-    assert tr.state.steps == 9 and not torch.equal(tr.state.ema[:100], tr.state.data[:100])
+    assert tr.state.steps == 9
+
+
+def test_ema_follows_the_reference_decay_schedule():
+    """ModelEMA.update (torch_utils.py:342-361): after update t, ema = d*ema + (1-d)*model with d = 0.9999*(1 - exp(-t/2000)), over every
+    float entry of the state_dict (parameters and BN running statistics)."""
+    import math
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    nc, B, S = 4, 2, 64
+    m = seed_state_dict_(DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', nc), verbose=False), 0).to(DEV)
+    tr = DetectionTrainer(m, lr0=0.02)
+    batch = dict(img=(seeded_images(B, S, S, seed=2) * 255).to(torch.uint8), **seeded_labels(B, nc, seed=6, max_boxes=4, min_boxes=2))
+    ema = tr.state.ema.cpu().double()
+    for t in range(1, 4):
+        tr.step(batch)
+        d = 0.9999 * (1 - math.exp(-t / 2000))
+        ema = (ema.float() * np.float32(d) + np.float32(1 - d) * tr.state.data.cpu()).double()        # fp32 arithmetic like v *= d; v += (1-d)*p
+        np.testing.assert_allclose(tr.state.ema.cpu().numpy(), ema.float().numpy(), rtol=2e-6, atol=1e-9)
+    assert not torch.equal(tr.state.ema, tr.state.data)
+    # the running statistics are part of it (ModelEMA walks state_dict(), not parameters())
+    assert tr.state.n_total > tr.state.n_param and not torch.equal(tr.state.ema[tr.state.n_param:], tr.state.data[tr.state.n_param:])
+
+
+def test_reference_training_call_sequence_reaches_the_hip_backward():
+    """`loss, items = model(batch); loss.backward()` (yolo/engine/trainer.py:334-343, nn/tasks.py:204-216): the reference trainer's own call
+    sequence fills every parameter gradient, equal bit for bit to the explicit model.backward(head_grads) path and within the usual bound
+    of CPU autograd through the oracle."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.utils.loss import loss_and_head_grads, v8DetectionLoss
+    name, nc, B, S = 'mspa_c2f_gd_yolov8', 4, 2, 64
+    x = seeded_images(B, S, S, seed=11)
+    lab = seeded_labels(B, nc, seed=4, max_boxes=4, min_boxes=2)
+    lab['bboxes'][:, 2:] = lab['bboxes'][:, 2:] * 0.5 + 0.1
+    mk = lambda: seed_state_dict_(DetectionModel(get_config(name, 'n', nc), verbose=False), 0).to(DEV).train()
+    # (a) the reference's call form
+    m = mk()
+    batch = dict(img=x.to(DEV), **lab)
+    loss, items = m(batch)
+    assert loss.requires_grad and items.shape == (3,)
+    loss.backward()
+    # (b) the explicit path on a fresh copy of the same model
+    m2 = mk()
+    feats = m2._predict_once(x.to(DEV))
+    total, _, hg = loss_and_head_grads(v8DetectionLoss(m2), feats, lab)
+    m2.backward(hg)
+    assert torch.equal(loss.detach(), total)
+    n = 0
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            continue
+        assert p.grad is not None and torch.equal(p.grad, p2.grad), k
+        n += 1
+    assert n > 150
+    # (c) CPU autograd through the oracle
+    strides = [float(s) for s in m.stride.tolist()]
+    _, _, ref_grads = _oracle_train_grads(name, nc, x, lab, strides)
+    for k, p in m.named_parameters():
+        if k in ref_grads:
+            g, r = p.grad.detach().cpu().double(), ref_grads[k].double()
+            assert (g - r).norm().item() / max(r.norm().item(), 1e-6 * r.numel() ** 0.5) < 2e-2, k
+    # every module dropped its saved activations; a forward without backward leaves nothing behind after the next forward either
+    assert all(not mod.__dict__.get('_ctx') for mod in m.modules())
+    m(batch); m(batch)[0].backward()
+    assert all(not mod.__dict__.get('_ctx') for mod in m.modules())
+    with torch.no_grad():
+        m(batch)
+    assert all(not mod.__dict__.get('_ctx') for mod in m.modules())
+    # gradient accumulation (trainer.py:250,345): a second backward adds when asked to
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.grad_accumulate = True
+    m(batch)[0].backward()
+    for k, p in m.named_parameters():
+        if k in g1 and 'bn' not in k:        # (BN batch statistics moved the running stats, not the gradients: same batch, same grads)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
 
 
 def test_packed_weight_caches_follow_the_hip_optimizer():

@@ -194,3 +194,117 @@ def test_tood_config_builds_and_oracle_dcn_reduces_to_conv():
     xs[:, :, :-1] = x[:, :, 1:]
     ref = F.conv2d(F.pad(xs, (1, 1, 1, 1)), w)
     assert (y1[:, :, 1:-1] - ref[:, :, 1:-1]).abs().max() < 1e-4      # interior rows: the borders differ by what each form pads
+
+
+# ------------------------------------------------------------------------------------------------ trainer host logic (no GPU call)
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_optimizer_groups_match_the_reference_build_optimizer(golden, tag):
+    """param_groups() vs the membership the reference's own BaseTrainer.build_optimizer produced on the reference's model
+    (tests/golden/optim_groups.npz, generated by gen_golden.py:optim_groups)."""
+    from mgdt_yolo_amd.yolo.engine.trainer import param_groups
+    g = golden('optim_groups')
+    m = tasks.DetectionModel(get_config(GI.E2E_MODELS[tag], 'n'), verbose=False)
+    mine = param_groups(m)
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    ref = {}
+    for gi, key in ((2, 'bias'), (0, 'decay'), (1, 'norm')):
+        for name in str(g[f'{tag}_{key}']).split('\n'):
+            ref[name] = gi
+    assert {k: v for k, v in mine.items() if k in trainable} == {k: v for k, v in ref.items() if k in trainable}
+    assert set(ref) >= trainable
+    if tag == 'mspa_c2f_gd_n':      # the reference rule decays the custom LayerNorm weight and GRN gamma/beta (plain nn.Modules)
+        assert mine['model.11.conv.1.norm.weight'] == 0 and mine['model.11.conv.1.grn.gamma'] == 0 and mine['model.11.conv.1.grn.beta'] == 0
+        assert mine['model.11.conv.1.norm.bias'] == 2 and mine['model.0.bn.weight'] == 1
+
+
+def test_trainer_warmup_and_accumulate_schedule():
+    """lr / bias-lr / momentum / accumulate per iteration as yolo/engine/trainer.py:250-251,284,317-326 computes them."""
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    m = tasks.DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', 4), verbose=False)
+    tr = DetectionTrainer(m, lr0=0.01, batch_size=16, nb=100, epochs=10)
+    assert tr.accumulate == 4 and tr.nw == 300
+    wd = tr.state.wd
+    off, k = tr.state.offsets['model.0.conv.weight']
+    assert torch.allclose(wd[off:off + k], torch.full((k,), 5e-4 * 16 * 4 / 64))            # decay scaled by batch*accumulate/nbs
+    off, k = tr.state.offsets['model.0.bn.bias']
+    assert (wd[off:off + k] == -1).all()                                                     # bias group marker
+    off, k = tr.state.offsets['model.0.bn.weight']
+    assert (wd[off:off + k] == 0).all()
+    tr.ni = 0; tr.warmup(0)
+    assert (tr.lr, tr.lr_bias, tr.mom, tr.accumulate) == (0.0, 0.1, 0.8, 1)
+    tr.ni = 150; tr.warmup(0)
+    assert tr.lr == pytest.approx(0.005) and tr.lr_bias == pytest.approx(0.055) and tr.mom == pytest.approx(0.8685) and tr.accumulate == 2
+    tr.ni = 300; tr.warmup(2)
+    lf2 = (1 - 2 / 10) * (1 - 0.01) + 0.01
+    assert tr.lr == pytest.approx(0.01 * lf2) and tr.lr_bias == pytest.approx(0.01 * lf2) and tr.mom == pytest.approx(0.937) and tr.accumulate == 4
+    tr.ni = 301; tr.warmup(3)
+    assert tr.lr == pytest.approx(0.01 * ((1 - 3 / 10) * 0.99 + 0.01)) and tr.accumulate == 4
+
+
+def _rank_trainer_exchange(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from mgdt_yolo_amd import parallel
+    from mgdt_yolo_amd.seeding import seed_state_dict_
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    dist = parallel.init('gloo')
+    m = seed_state_dict_(tasks.DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', 4), verbose=False), rank)     # ranks start DIFFERENT
+    tr = DetectionTrainer(m, world_size=world)
+    st, ex = tr.state, tr.exchange
+    start = st.data.clone()
+    n_layers = len(m.model)
+    res = []
+    for step in range(2):                       # two DetectionTrainer.step-shaped exchanges with unequal per-rank gradients
+        g = torch.Generator().manual_seed(100 * step + rank)
+        full = torch.randn(st.n_param, generator=g)
+        st.grad.zero_()
+        ends = [st.layer_end.get(i) for i in range(n_layers)]
+        for i in reversed(range(n_layers)):     # the reverse pass: layer i's slice of the flat buffer is written, then the hook fires
+            hi = ends[i]
+            if hi is not None:
+                lo = max([e for e in ends[:i] if e is not None], default=0)
+                st.grad[lo:hi] = full[lo:hi]
+            ex.layer_done(i)
+        ex.finish()
+        res.append(st.grad.clone())
+    q.put((rank, start.numpy(), [r.numpy() for r in res], ex.slices))
+    dist.destroy_process_group()
+
+
+def test_trainer_broadcast_and_bucketed_all_reduce_gloo_world2():
+    """DDP-style start (rank 0's parameters and buffers everywhere, trainer.py:225) and the layer-ordered bucketed all-reduce of the flat
+    gradient buffer hung on BaseModel.backward's layer_done hook: two exchanges, unequal gradients, result = mean over ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 90
+    ps = [ctx.Process(target=_rank_trainer_exchange, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=180) for _ in ps), key=lambda t: t[0])
+    [p.join(30) for p in ps]
+    (_, s0, g0, slices), (_, s1, g1, _) = res
+    assert np.array_equal(s0, s1)                                          # rank 1 now holds rank 0's weights
+    assert len(slices) >= 2 and slices[0][1] == 0 and all(a[2] == b[1] for a, b in zip(slices[:-1], slices[1:]))   # contiguous cover
+    n = g0[0].shape[0]
+    assert slices[-1][2] == n
+    for step in range(2):
+        want = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(2)).numpy() / 2
+        np.testing.assert_allclose(g0[step], want, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(g0[step], g1[step])
+
+
+def test_bench_refuses_to_report_fewer_ranks_than_requested():
+    """`python bench.py --gpus 2`: under a launcher with the wrong world size it exits non-zero before touching the GPU; without a launcher
+    it starts the ranks itself as a child (torch.distributed.run) - on this GPU-less box they fail, so the parent must exit non-zero and
+    print no JSON line (never a 1-GPU number under n_gpus 2)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, 'bench.py')
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'refusing to report' in r.stderr and '"value"' not in r.stdout
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"value"' not in r.stdout
+    assert 'torch.distributed' in r.stderr or 'ChildFailedError' in r.stderr or 'Traceback' in r.stderr      # the child launcher really ran

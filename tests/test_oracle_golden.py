@@ -73,6 +73,9 @@ def _oracle_module(name, cls, args, sd, xs):
     if cls == 'Conv':
         act = 'silu' if len(args) < 8 else {'relu': 'relu', False: 'none'}[args[7]]
         return OL.conv(x, sd, 'm', s=args[3], act=act)
+    if cls == 'DWConv':     # conv.py:82-86: Conv with groups = gcd(c1, c2)
+        import math
+        return OL.conv(x, sd, 'm', s=args[3], g=math.gcd(args[0], args[1]))
     if cls == 'Bottleneck':
         return OL.bottleneck(x, sd, 'm', args[2])
     if cls == 'C2f':
@@ -183,6 +186,24 @@ def test_greedy_nms_properties():
         assert (iou_d[j][keep < d] > 0.5 - 1e-6).any()
     assert np.array_equal(ON.greedy_nms(b[keep], 0.5), np.arange(len(keep)))   # idempotent
     assert len(ON.greedy_nms(np.zeros((0, 4), np.float32), 0.5)) == 0
+
+
+def test_compiled_greedy_nms_equals_the_numpy_restatement(golden):
+    """oracle/csrc/greedy_nms.c (used by the timed CPU baseline) == oracle.nms.greedy_nms, kept positions bit for bit, incl. the early stop."""
+    r = np.random.default_rng(3)
+    for n in (0, 1, 7, 400, 3000):
+        c = r.uniform(0, 300, (n, 2)); wh = r.uniform(5, 80, (n, 2))
+        b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+        for thr in (0.3, 0.7):
+            full = ON.greedy_nms(b, thr)
+            assert np.array_equal(ON.greedy_nms_c(b, thr), full)
+            assert np.array_equal(ON.greedy_nms_c(b, thr, limit=50), full[:50])
+    y = golden('e2e_mspa_c2f_gd_n')['y_2x160x160']
+    for cname, kw in GI.NMS_CASES:
+        a, ka = ON.non_max_suppression(y, return_index=True, **kw)
+        b_, kb = ON.non_max_suppression(y, return_index=True, compiled=True, **kw)
+        for u, v, (ia, ca), (ib, cb) in zip(a, b_, ka, kb):
+            assert np.array_equal(u, v) and np.array_equal(ia, ib) and np.array_equal(ca, cb), cname
 
 
 def test_validator_matching_matches_reference(golden):
