@@ -260,7 +260,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
                                                              const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh,
-                                                             long ysw, FastDiv fd_q, FastDiv fd_w) {
+                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit) {
   extern __shared__ float sm[];
   const int n = blockIdx.y, cw = C / G, hid = cw / 4;
   float* pooled = sm;               // [C][5] means
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   const float cnt[5] = {(float)H * W, (float)he0 * we0, (float)he0 * (W - ws1), (float)(H - hs1) * we0, (float)(H - hs1) * (W - ws1)};
   for (int i = threadIdx.x; i < C * 5; i += 256) {
     float sum = 0.f;
-    for (int sp = 0; sp < SPR_SPLITS; ++sp) sum += partial[((long)n * SPR_SPLITS + sp) * C * 5 + i];
+    for (int sp = 0; sp < nsplit; ++sp) sum += partial[((long)n * nsplit + sp) * C * 5 + i];
     pooled[i] = sum / cnt[i % 5];
   }
   __syncthreads();
@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   }
 }
 
-extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
                                        const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (nsplit <= 0) nsplit = SPR_SPLITS;
   if (!pooled || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "spr_attn_scale: null/empty argument");
   const int c = x->c;
   if (groups < 1 || c % groups || (c / groups) % 4 || c > 4096) MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: c=%d groups=%d", c, groups);
@@ -347,7 +348,7 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, const float* fc1_w, 
     const int K = (int)std::max<long>(1, std::min<long>(64, vecs / per_wg));
     spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
                                                                               x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
-                                                                              make_fastdiv((uint32_t)x->w));
+                                                                              make_fastdiv((uint32_t)x->w), nsplit);
   });
   MGDT_CHECK_LAUNCH("spr_attn_scale_fwd");
   return MGDT_OK;

@@ -287,7 +287,12 @@ extern "C" int mgdt_dcnv2_mfma_fwd(const mgdt_view* x, const mgdt_view* offset_m
   const long M = (long)x->n * x->h * x->w;
   const int grid = (int)std::min<long>(cdiv(M, 64), 2048);
   const size_t lds = (size_t)nchunks * NB * 1024;
-  if (lds > 64 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "dcnv2_mfma: weight panel %zu B does not fit", lds);
+  if (lds > 144 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "dcnv2_mfma: weight panel %zu B does not fit", lds);
+  if (lds > 64 * 1024) {      // 64 -> 64 channels (the scale-s head): 72 KiB of dynamic LDS needs the opt-in (idempotent, same value from every caller)
+    const void* ks[4] = {(const void*)dcnv2_mfma_kernel<1>, (const void*)dcnv2_mfma_kernel<2>, (const void*)dcnv2_mfma_kernel<3>, (const void*)dcnv2_mfma_kernel<4>};
+    hipError_t e = hipFuncSetAttribute(ks[NB > 4 ? 3 : NB - 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "dcnv2_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
 #define DCN_L(B) dcnv2_mfma_kernel<B><<<grid, 256, lds, (hipStream_t)s>>>((const bf16*)x->p, x->sn, x->sh, x->sw, (const bf16*)offset_mask->p, offset_mask->sn, \
                                                                          offset_mask->sh, offset_mask->sw, (const char*)packed_w, (bf16*)y->p, y->sn, y->sh, y->sw, \
                                                                          x->n, x->h, x->w, x->c, nchunks)

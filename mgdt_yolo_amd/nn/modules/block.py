@@ -16,6 +16,22 @@ __all__ = ('DFL', 'SPPF', 'C2f', 'MSPA_C2f', 'Bottleneck', 'SimFusion_4in', 'Sim
            'InjectionMultiSum_Auto_pool', 'Upsample')
 
 
+def _plain_block(first, last, bottlenecks):
+    """True when a CSP block is made of what mgdt_csp_block_fwd computes: 1x1 Conv+BN+act at both ends, bottlenecks of two dense 3x3 Conv+BN
+    with the same activation and one shortcut setting."""
+    def conv_ok(c, k):
+        return (isinstance(c, Conv) and hasattr(c, 'bn') and c.conv.kernel_size == (k, k) and c.conv.stride == (1, 1) and c.conv.groups == 1
+                and c.conv.bias is None and act_code(c.act) == a0)
+    try:
+        a0 = act_code(first.act)
+    except RuntimeError:
+        return False
+    if not (conv_ok(first, 1) and conv_ok(last, 1)) or len(bottlenecks) == 0:
+        return False
+    return all(isinstance(m, Bottleneck) and conv_ok(m.cv1, 3) and conv_ok(m.cv2, 3) and m.add == bottlenecks[0].add
+               and m.cv1.conv.in_channels == m.cv1.conv.out_channels == m.cv2.conv.out_channels for m in bottlenecks)
+
+
 class DFL(nn.Module):
     """Integral module of Distribution Focal Loss (reference block.py:36-54): parameter container; the
     softmax-expectation is fused into the Detect decode kernel."""
@@ -70,7 +86,14 @@ class C2f(HipModule):
         b, _, h, w = x.shape
         c, n = self.c, len(self.m)
         train = self.training and hasattr(self.cv1, 'bn')
-        cat = ops.new_act(b, (2 + n) * c, h, w, self.cv1.out_dtype(x), x.device)
+        dt = self.cv1.out_dtype(x)
+        if not train and _plain_block(self.cv1, self.cv2, self.m) and ops.csp_block_supported(ops.CSP_C2F, x, self.cv2.conv.out_channels, c, n, dt):
+            # the whole block in one launch: cv1, the bottleneck chain on LDS-resident tiles, cv2 over the concat (mgdt_csp_block_fwd)
+            mids = [pk for m in self.m for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
+            pk1 = self.cv1.packed(dt, False)
+            return ops.csp_block(ops.CSP_C2F, x, pk1.w, pk1.bias, mids, self.m[0].add, self.cv2.packed(dt, False), c, act_code(self.cv1.act),
+                                 self.cv2.conv.out_channels, False)[0]
+        cat = ops.new_act(b, (2 + n) * c, h, w, dt, x.device)
         (self.cv1.train_fwd if train else self.cv1.run)(x, out=cat[:, :2 * c])
         for j, m in enumerate(self.m):
             m.run(cat[:, (1 + j) * c:(2 + j) * c], out=cat[:, (2 + j) * c:(3 + j) * c])
@@ -117,7 +140,16 @@ class MSPA_C2f(HipModule):
         wd, s, n = self.inwidth, self.nums, self.btnk_nums
         train = self.training and hasattr(self.convs[0], 'bn')
         run = (lambda m: m.train_fwd) if train else (lambda m: m.run)
-        cat = ops.new_act(b, (s - 1 + n) * wd, h, w, self.convs[0].out_dtype(x), x.device)
+        dt = self.convs[0].out_dtype(x)
+        at = self.attention
+        if (not train and s == 4 and self.inwidth == self.outwidth and self._chain_ok() and _plain_block(self.convs[0], self.convs[3], self.bottleneck)
+                and ops.csp_block_supported(ops.CSP_MSPA, x, self.convs[3].conv.out_channels, wd, n, dt)):
+            # one launch for the block (mgdt_csp_block_fwd) + one for attention MLP and scaling; the pooled sums come out of the block kernel
+            mids = [pk for m in self.bottleneck for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
+            out, pool, tiles = ops.csp_block(ops.CSP_MSPA, x, self._packed_chain(dt).blob, None, mids, self.bottleneck[0].add, self.convs[3].packed(dt, False),
+                                             wd, act_code(self.convs[0].act), self.convs[3].conv.out_channels, True)
+            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, part=pool, nsplit=tiles)
+        cat = ops.new_act(b, (s - 1 + n) * wd, h, w, dt, x.device)
         # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
         if not train and s == 4 and ops.pw_chain_supported(wd, cat.dtype) and x.dtype == cat.dtype and self._chain_ok():
             ops.pw_chain3(x[:, :3 * wd], self._packed_chain(cat.dtype), act_code(self.convs[0].act), cat[:, :3 * wd])   # one launch
@@ -132,7 +164,6 @@ class MSPA_C2f(HipModule):
             m.run(src, out=dst, x2=pending)
             src, pending = dst, None
         out = run(self.convs[s - 1])(cat)
-        at = self.attention
         if train:
             attn, part = ops.spr_attention_train(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
             self._save_ctx((out, attn, part, x.shape))

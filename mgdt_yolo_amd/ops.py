@@ -202,15 +202,51 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     return attn
 
 
-def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None):
-    """out = x * softmax_over_groups(SPR(x_group)): pooling pass, then attention MLP + scaling in one launch."""
+def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=None, nsplit=0):
+    """out = x * softmax_over_groups(SPR(x_group)): pooling pass (skipped when the producing kernel already left its per-tile sums in
+    `part`, fp32 [b][nsplit][c][5]), then attention MLP + scaling in one launch."""
     b, c, h, w = x.shape
-    part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
-    _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
+    if part is None:
+        part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
+        _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
+        nsplit = L.SPR_SPLITS
     out = like(x) if out is None else out
-    _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
+    _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), int(nsplit), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
             dtype_code(x.dtype), stream())
     return out
+
+
+# ------------------------------------------------------------------ whole CSP block (MSPA_C2f / C2f) in one launch
+FUSED_CSP_BLOCK = True   # tests flip this to compare against the per-conv launch chain
+CSP_MSPA, CSP_C2F = 0, 1
+
+
+def csp_block_supported(mode, x, cout, wd, nbtl, dtype):
+    return bool(FUSED_CSP_BLOCK and dtype == torch.bfloat16 and x.dtype == dtype and is_nhwc(x) and
+                L.lib().mgdt_csp_block_supported(mode, x.shape[1], int(cout), int(wd), int(nbtl), x.shape[2], x.shape[3], dtype_code(dtype)))
+
+
+def csp_block(mode, x, front, front_bias, mids, shortcut, back, wd, act, cout, want_pool):
+    """mgdt_csp_block_fwd: `front` = PackedPwChain.blob (MSPA) or PackedConv (C2f); `mids` = PackedConv list of the bottlenecks' 3x3 convs;
+    `back` = PackedConv of the 1x1 over the concat.  Returns (y, pool partials or None, tiles)."""
+    lib = L.lib()
+    b, cin, h, w = x.shape
+    nb = len(mids) // 2
+    tiles = lib.mgdt_csp_block_tiles(mode, b, cin, cout, wd, nb, h, w, None)
+    if tiles <= 0:
+        raise RuntimeError('csp_block: configuration not covered')
+    y = new_act(b, cout, h, w, x.dtype, x.device)
+    pool = torch.empty(b * tiles * cout * 5, dtype=torch.float32, device=x.device) if want_pool else None
+    marr = (C.c_void_p * len(mids))(*[m.w.data_ptr() for m in mids])
+    barr = (C.c_void_p * len(mids))(*[m.bias.data_ptr() for m in mids])
+    if _PROF is not None:
+        es = x.element_size()
+        catc = (3 if mode == CSP_MSPA else 2) * wd + nb * wd
+        fl = 2.0 * b * h * w * ((3 * wd * wd if mode == CSP_MSPA else cin * 2 * wd) + 2 * nb * 9 * wd * wd + catc * cout)
+        _META['csp_block_fwd'] = dict(shape=(b, cin, h, w, cout, wd, nb), flops=fl, bytes=float(b * h * w * (cin + cout) * es))
+    _launch('csp_block_fwd', 'mgdt_csp_block_fwd', mode, vp(x), ptr(front), ptr(front_bias), marr, barr, nb, int(bool(shortcut)), ptr(back.w), ptr(back.bias),
+            int(wd), act, vp(y), ptr(pool), dtype_code(x.dtype), stream())
+    return y, pool, tiles
 
 
 def scale_channels(x, attn, out=None):

