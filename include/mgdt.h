@@ -79,18 +79,19 @@ int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packe
 /* ---- a whole CSP block (MSPA_C2f / C2f) in one launch, bf16 inference (nn/modules/block.py:187-287, :514-526):
  *   mode 0 (MSPA_C2f): front = the three chained 1x1 convs of mgdt_pw_chain3_fwd (blob of mgdt_pw_chain_pack), bottleneck input
  *                      sp2 + x[3wd:4wd]; concat = [sp0 | sp1 | sp2 | b_0 .. b_{n-1}]
- *   mode 1 (C2f):      front = cv1 (mgdt_conv_pack panel cin -> 2wd + bias), bottleneck input = its second half;
- *                      concat = [cv1 output | b_0 .. b_{n-1}]
+ *   mode 1 (C2f):      x = cv1's output (2wd channels, computed by mgdt_conv2d_fwd), front / front_bias unused (NULL); bottleneck
+ *                      input = its second half; concat = [x | b_0 .. b_{n-1}]
  *   then n bottlenecks (two 3x3 convs wd -> wd each, mgdt_conv_pack panels mid[2n] in execution order, residual add when `shortcut`)
  *   and the 1x1 conv `back` over the concat -> y.  One workgroup computes one spatial tile of one image with the halo (2n pixels)
  *   recomputed; nothing but x is read from and nothing but y written to HBM.  All convs share `act`.
- *   pool: NULL, or fp32 [n][tiles][cout][5] partial sums of y in the layout of mgdt_spr_pool_fwd with `tiles` row-band slots
- *   (tiles = mgdt_csp_block_tiles(...), which also reports {TH, TW, RH, RW, lds bytes, workgroups} in geom6 when non-NULL);
- *   feed it to mgdt_spr_attn_scale_fwd(..., nsplit = tiles).  mode 0 needs even h, w (a tile lies inside one pooling bin).
- *   mgdt_csp_block_supported: 1 when covered (bf16; wd in {8,16,32,64}; n in {1,2}; mode 0: cin == 4wd; mode 1: cin % 32 == 0,
- *   cin <= 256, wd >= 16); otherwise callers keep the per-conv launches. */
+ *   pool: NULL, or fp32 [n][slots][cout]: channel sums of y per tile (slot = tile * (slots / tiles) + k, tiles in row-major order);
+ *   slots = mgdt_csp_block_tiles(...), which also reports {TH, TW, RH, RW, lds bytes, workgroups, tiles_x, tiles_y} in geom8 when
+ *   non-NULL; feed it to mgdt_spr_attn_scale_fwd(pool, slots, tiles_x, tiles_y, ...).  mode 0 needs even h, w and picks an even
+ *   tile grid (every tile lies inside one adaptive_avg_pool2d(2) bin).
+ *   mgdt_csp_block_supported: 1 when covered (bf16; wd in {8,16,32,64}; n in {1,2}; mode 0: cin == 4wd; mode 1: cin == 2wd,
+ *   wd >= 16); otherwise callers keep the per-conv launches. */
 int mgdt_csp_block_supported(int mode, int cin, int cout, int wd, int nbtl, int h, int w, int dtype);
-int mgdt_csp_block_tiles(int mode, int n, int cin, int cout, int wd, int nbtl, int h, int w, int* geom6);
+int mgdt_csp_block_tiles(int mode, int n, int cin, int cout, int wd, int nbtl, int h, int w, int* geom8);
 int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* front, const float* front_bias, const void* const* mid,
                        const float* const* mid_bias, int nbtl, int shortcut, const void* back, const float* back_bias, int wd, int act,
                        const mgdt_view* y, float* pool, int dtype, mgdt_stream s);
@@ -159,8 +160,9 @@ int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const float* fc1_
 int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, const mgdt_view* y, int dtype, mgdt_stream s);
 /* spr_attn + scale_channels in one launch: every workgroup recomputes its image's attention (same order, same bits) and scales
  * a share of the pixels: y = x * softmax_groups(SPR(pooled)).  `pooled` as written by mgdt_spr_pool_fwd (nsplit = MGDT_SPR_SPLITS, or 0)
- * or by mgdt_csp_block_fwd (nsplit = its tile count): fp32 [n][nsplit][c][5]. */
-int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+ * with tiles_x = tiles_y = 0: fp32 [n][nsplit][c][5]; or the per-tile sums of mgdt_csp_block_fwd: fp32 [n][nsplit][c], tiles_x x tiles_y
+ * its tile grid. */
+int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tiles_x, int tiles_y, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
                             const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
 
 /* ---- SPPF pooling: y1,y2,y3 = maxpool5(x), maxpool5(y1), maxpool5(y2) (nn/modules/block.py:138-153) ----- */

@@ -2,7 +2,7 @@
 // CU.  Reference: nn/modules/block.py:209-287 (MSPA_C2f), :187-207 (C2f), :514-526 (Bottleneck).
 //
 //   front   MSPA: sp0 = cv0(x0), sp1 = cv1(sp0 + x1), sp2 = cv2(sp1 + x2)   (register-chained MFMAs, as mgdt_pw_chain3_fwd)
-//           C2f : [y0 | y1] = cv1(x)                                          (1x1 conv, activations global -> VGPR)
+//           C2f : [y0 | y1] = cv1(x) comes from the ordinary 1x1 conv launch; the front copies it into the tile buffers
 //   middle  n bottlenecks, each two 3x3 convs wd -> wd (+ shortcut), on LDS-resident maps of the tile + halo
 //   back    1x1 conv over the concat [front outputs | bottleneck outputs] -> Cout, written to HBM; MSPA: per-tile channel sums for
 //           the SPR pooling attention (the block output is never re-read for pooling)
@@ -19,6 +19,9 @@
 // channels of one pixel = one 8-byte LDS / HBM store.  Each wave keeps the weight fragments of ONE cout block of the running conv in
 // registers (weights-stationary: 12..72 VGPRs) and streams pixel groups through them; the packed panels are the ordinary
 // mgdt_conv_pack layout, read straight from L2.  Pixels outside the image are written as zeros (the next conv's zero padding).
+#include <algorithm>
+#include <vector>
+
 #include "conv_igemm_kernel.h"
 
 struct CspArgs {
@@ -31,17 +34,19 @@ struct CspArgs {
   int N, H, W, Cin, Cout, wd, nbtl, shortcut, act;
   int TH, TW, halo, RH, RW, tiles_x, tiles_y, total_tiles, per_xcd;
   int catC, nchb, nbo;                 // concat channels, K chunks / cout blocks of the back conv
-  int front_nch, front_nb;             // C2f front: K chunks (Cin / 32) and cout blocks (2c / 16)
   int RPA, TPA, PS, CS;                // allocated region / tile pixels, pixel strides (bytes) of P/T and of the concat buffer
   int chain_words;                     // MSPA: 16-byte words of the chain blob's weight part
+  unsigned long long* dbg;             // MGDT_CSP_DBG: 8 wall-clock stamps (10 ns units) per workgroup
+  int pool_gst;                        // back phase: waves per cout block = pool slots per tile (1 when there are >= 8 cout blocks)
 };
 
 constexpr int CSP_THREADS = 512;
 constexpr int CSP_NW = CSP_THREADS / 64;
-constexpr int CSP_NCHB_MAX = 8;        // back conv: K <= 256 concat channels
-constexpr int CSP_FRONT_NCH_MAX = 8;   // C2f front: Cin <= 256
+constexpr int CSP_NCHB_MAX = 8;        // back conv: K <= 256 concat channels (host-side bound)
 
-__device__ __forceinline__ float csp_act(float v, int act) { return act == MGDT_ACT_SILU ? v * fast_sigmoid(v) : act_apply(v, act); }
+// SiLU only, branch-free (the host refuses anything else): a run-time activation switch here turned every epilogue into four serial
+// branchy exp -> rcp chains; as straight-line code the four values' transcendentals interleave
+__device__ __forceinline__ float csp_act(float v, int) { return v * fast_sigmoid(v); }
 
 typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int csp_raw2;
 
@@ -58,8 +63,9 @@ __device__ __forceinline__ f32x4 lds_load4(const char* p) {
 
 // MODE 0 = MSPA_C2f, 1 = C2f.  WD = bottleneck width (8, 16, 32, 64).
 template <int WD, int MODE>
-__global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a) {
+__global__ __launch_bounds__(CSP_THREADS, ((WD <= 16 || (WD == 32 && MODE == 1)) ? 4 : 2)) void csp_block_kernel(const CspArgs a) {   // 4: two workgroups per CU (<= 128 VGPRs) where LDS allows it
   constexpr int CP = WD / 8;                         // 16-byte pieces per tap
+  constexpr int NCHB = WD == 8 ? 2 : (WD == 16 ? 3 : (WD == 32 ? 5 : 8));   // K chunks of the back conv at n = 2 (concat <= 256 channels)
   constexpr int NB = WD >= 16 ? WD / 16 : 1;         // cout blocks of a wd -> wd conv
   constexpr int NCH = (9 * CP + 3) / 4;              // K chunks of a 3x3 conv
   constexpr int NBK = NB, KC = (NBK + 1) / 2;        // pw chain geometry (mlp_chain.hip)
@@ -84,6 +90,16 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
   const int n = tlin / tpi, trem = tlin - n * tpi;
   const int ty0 = (trem / a.tiles_x) * a.TH, tx0 = (trem % a.tiles_x) * a.TW;
   const int RP = a.RH * a.RW, TP = a.TH * a.TW;
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg && tid == 0) a.dbg[(size_t)tlin * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
+
+  // weights-stationary: this wave's cout block of the running 3x3 conv lives in registers.  Every conv's fragments are requested one
+  // phase AHEAD (the first ones right here, before the tables and the front), so no phase starts by waiting on L2.
+  const int nbv = wave % NB, gvm = wave / NB, gstm = CSP_NW / NB;
+  bf16x8 A[NCH];
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) A[kc] = *(const bf16x8*)(a.mid[0] + ((size_t)(kc * NB + nbv) * 64 + lane) * 16);
+  f32x4 bias = *(const f32x4*)(a.mid_bias[0] + nbv * 16 + 4 * g);
 
   // ---- tables, zero fill, chain weights
   for (int q = tid; q < a.RPA; q += CSP_THREADS) {
@@ -109,6 +125,7 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
     for (int i = tid; i < 3 * NBK * 16; i += CSP_THREADS) bl[i] = ((const float*)(a.front + (size_t)a.chain_words * 16))[i];
   }
   __syncthreads();
+  stamp(1);
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
@@ -116,88 +133,122 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
 
   // ================================================================ front
   if (MODE == 0) {
+    // each wave takes a contiguous run of pixel groups and requests the inputs of U groups before it touches the first one: the phase is
+    // bound by HBM/L2 latency, not by work (a wave that waits for one group at a time leaves the CU with 16 requests in flight)
+    constexpr int U = WD == 64 ? 2 : (WD == 32 ? 3 : 5);
     const char* const wlane = wl + lane * 16;
     const float* bl = (const float*)(wl + (size_t)a.chain_words * 16);
-    for (int grp = wave; grp < ngr; grp += CSP_NW) {
-      const int q = grp * 16 + r;
-      const int go = goff[q];                                     // q < RPA always (RPA is padded to whole groups)
-      const int ct = ctab[q];
-      f32x4 X[4][NBK];
+    const int per = ngr / CSP_NW, rem = ngr - per * CSP_NW;   // balanced: the first `rem` waves take one group more
+    const int gbeg = wave * per + min(wave, rem), gend = gbeg + per + (wave < rem ? 1 : 0);
+    for (int g0 = gbeg; g0 < gend; g0 += U) {
+      int go[U], ct[U];
+      csp_raw2 XR[U][4][NBK];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int u = 0; u < U; ++u) {
+        const bool gv_ = g0 + u < gend;
+        const int q = (g0 + u) * 16 + r;
+        go[u] = gv_ ? goff[q] : MGDT_OOB;
+        ct[u] = gv_ ? (int)ctab[q] : -1;
 #pragma unroll
-        for (int blk = 0; blk < NBK; ++blk) {
-          const int c = blk * 16 + 4 * g;
-          const int dead = c >= WD ? MGDT_OOB : 0;
-          X[i][blk] = bload4<bf16>(xrs, (uint32_t)(go | dead) + (uint32_t)((i * WD + c) * 2));
-        }
-      f32x4 prev[NBK];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        bf16x8 Bf[KC];
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int blk = kc * 2 + e / 4;
-            float vv = 0.f;
-            if (blk < NBK) vv = X[i][blk][e % 4] + (i ? prev[blk][e % 4] : 0.f);
-            Bf[kc][e] = (bf16)vv;
+          for (int blk = 0; blk < NBK; ++blk) {
+            const int c = blk * 16 + 4 * g;
+            const int dead = c >= WD ? MGDT_OOB : 0;
+            XR[u][i][blk] = __builtin_amdgcn_raw_buffer_load_b64(xrs, (uint32_t)(go[u] | dead) + (uint32_t)((i * WD + c) * 2), 0, 0);
           }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (g0 + u >= gend) break;                               // wave-uniform
+        const int q = (g0 + u) * 16 + r;
+        f32x4 X[4][NBK];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int blk = 0; blk < NBK; ++blk) {
+            const bf16x4 o = __builtin_bit_cast(bf16x4, XR[u][i][blk]);
+            X[i][blk] = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+          }
+        f32x4 prev[NBK];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          bf16x8 Bf[KC];
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int blk = kc * 2 + e / 4;
+              float vv = 0.f;
+              if (blk < NBK) vv = X[i][blk][e % 4] + (i ? prev[blk][e % 4] : 0.f);
+              Bf[kc][e] = (bf16)vv;
+            }
+#pragma unroll
+          for (int ob = 0; ob < NBK; ++ob) {
+            f32x4 acc = *(const f32x4*)(bl + (i * NBK + ob) * 16 + 4 * g);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) acc = mma(*(const bf16x8*)(wlane + ((i * KC + kc) * NBK + ob) * 1024), Bf[kc], acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (float)(bf16)csp_act(acc[j], a.act);
+            prev[ob] = acc;
+            const int c = ob * 16 + 4 * g;
+            if (c < WD && ct[u] >= 0) lds_store4(catb + ct[u] * a.CS + (i * WD + c) * 2, acc);
+          }
+        }
+        // bottleneck input = sp2 + x3 (the pending add of block.py:259), zero outside the image
 #pragma unroll
         for (int ob = 0; ob < NBK; ++ob) {
-          f32x4 acc = *(const f32x4*)(bl + (i * NBK + ob) * 16 + 4 * g);
-#pragma unroll
-          for (int kc = 0; kc < KC; ++kc) acc = mma(*(const bf16x8*)(wlane + ((i * KC + kc) * NBK + ob) * 1024), Bf[kc], acc);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = (float)(bf16)csp_act(acc[j], a.act);
-          prev[ob] = acc;
           const int c = ob * 16 + 4 * g;
-          if (c < WD && ct >= 0) lds_store4(catb + ct * a.CS + (i * WD + c) * 2, acc);
+          f32x4 p0 = prev[ob] + X[3][ob];
+          if (go[u] == MGDT_OOB) p0 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (c < WD) lds_store4(Pb + q * a.PS + c * 2, p0);
         }
-      }
-      // bottleneck input = sp2 + x3 (the pending add of block.py:259), zero outside the image
-#pragma unroll
-      for (int ob = 0; ob < NBK; ++ob) {
-        const int c = ob * 16 + 4 * g;
-        f32x4 p0 = prev[ob] + X[3][ob];
-        if (go == MGDT_OOB) p0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < WD) lds_store4(Pb + q * a.PS + c * 2, p0);
       }
     }
   } else {
-    // C2f front: 1x1 conv Cin -> 2c over the region; wave = (cout block, pixel-group phase)
-    const int nbv = wave % a.front_nb, gv = wave / a.front_nb, gst = CSP_NW / a.front_nb;
-    bf16x8 A[CSP_FRONT_NCH_MAX];
+    // C2f: x is cv1's output [y0 | y1] (2*WD channels, written by the 1x1 conv launch in front of this one: a wide streaming GEMM that
+    // gains nothing from living here); the front copies the tile's own pixels into the concat buffer and y1 (+ halo) into P
+    constexpr int NB2 = 2 * WD / 16;
+    constexpr int U = WD == 64 ? 2 : 4;
+    const int per = ngr / CSP_NW, rem = ngr - per * CSP_NW;
+    const int gbeg = wave * per + min(wave, rem), gend = gbeg + per + (wave < rem ? 1 : 0);
+    for (int g0 = gbeg; g0 < gend; g0 += U) {
+      int go[U], ct[U];
+      csp_raw2 XR[U][NB2];
 #pragma unroll
-    for (int kc = 0; kc < CSP_FRONT_NCH_MAX; ++kc)
-      if (kc < a.front_nch) A[kc] = *(const bf16x8*)(a.front + ((size_t)(kc * a.front_nb + nbv) * 64 + lane) * 16);
-    const f32x4 bias = *(const f32x4*)(a.front_bias + nbv * 16 + 4 * g);
-    const int cc = nbv * 16 + 4 * g;                             // output channel of the 2c-wide cv1 output
-    for (int grp = gv; grp < ngr; grp += gst) {
-      const int q = grp * 16 + r;
-      const int go = goff[q];
-      const int ct = ctab[q];
-      bf16x8 Bf[CSP_FRONT_NCH_MAX];
+      for (int u = 0; u < U; ++u) {
+        const bool gv_ = g0 + u < gend;
+        const int q = (g0 + u) * 16 + r;
+        go[u] = gv_ ? goff[q] : MGDT_OOB;
+        ct[u] = gv_ ? (int)ctab[q] : -1;
 #pragma unroll
-      for (int kc = 0; kc < CSP_FRONT_NCH_MAX; ++kc)
-        if (kc < a.front_nch) Bf[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, (uint32_t)go + (uint32_t)((kc * 4 + g) * 16), 0, 0));
-      f32x4 acc = bias;
+        for (int blk = 0; blk < NB2; ++blk)
+          XR[u][blk] = __builtin_amdgcn_raw_buffer_load_b64(xrs, (uint32_t)go[u] + (uint32_t)((blk * 16 + 4 * g) * 2), 0, 0);   // zeros outside the image
+      }
 #pragma unroll
-      for (int kc = 0; kc < CSP_FRONT_NCH_MAX; ++kc)
-        if (kc < a.front_nch) acc = mma(A[kc], Bf[kc], acc);
+      for (int u = 0; u < U; ++u) {
+        if (g0 + u >= gend) break;                               // wave-uniform
+        const int q = (g0 + u) * 16 + r;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = csp_act(acc[j], a.act);
-      if (go == MGDT_OOB) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ct >= 0) lds_store4(catb + ct * a.CS + cc * 2, acc);
-      if (cc >= WD) lds_store4(Pb + q * a.PS + (cc - WD) * 2, acc);          // second half = the bottleneck chain's input (block.py:201-203)
+        for (int blk = 0; blk < NB2; ++blk) {
+          const int cc = blk * 16 + 4 * g;
+          if (ct[u] >= 0) *(csp_raw2*)(catb + ct[u] * a.CS + cc * 2) = XR[u][blk];
+          if (cc >= WD) *(csp_raw2*)(Pb + q * a.PS + (cc - WD) * 2) = XR[u][blk];      // second half = the bottleneck chain's input (block.py:201-203)
+        }
+      }
     }
   }
+  stamp(2);
   __syncthreads();
+  stamp(3);
 
   // ================================================================ middle: 2 * nbtl 3x3 convs, P -> T -> P ...
+  constexpr bool PREB = WD <= 16;                                // prefetch the back conv's first fragments too (register budget)
+  bf16x8 AB[NCHB];
+  f32x4 biasB = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int bgst = a.pool_gst, bgv = wave / (CSP_NW / bgst), obst = CSP_NW / bgst, ob0 = wave % obst;
   {
-    const int nbv = wave % NB, gv = wave / NB, gst = CSP_NW / NB;
+    const int gv = gvm, gst = gstm;
     int boff[NCH];                                               // this lane's byte offset of chunk kc's piece relative to its pixel
 #pragma unroll
     for (int kc = 0; kc < NCH; ++kc) {
@@ -211,19 +262,28 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
     for (int j = 0; j < 2 * a.nbtl; ++j) {
       const char* in = (j & 1) ? Tb : Pb;
       char* out = (j & 1) ? Pb : Tb;
-      bf16x8 A[NCH];
+      // narrow convs: the next conv's fragments are requested now and land while this conv computes (wide ones: registers are better
+      // spent on two workgroups per CU, their fragments are loaded after the barrier)
+      constexpr bool PREN = WD <= 16;
+      bf16x8 An[PREN ? NCH : 1];
+      f32x4 biasn = bias;
+      const bool more = j + 1 < 2 * a.nbtl;                     // uniform
+      if (more) {
+        if (PREN) {
 #pragma unroll
-      for (int kc = 0; kc < NCH; ++kc) A[kc] = *(const bf16x8*)(a.mid[j] + ((size_t)(kc * NB + nbv) * 64 + lane) * 16);
-      const f32x4 bias = *(const f32x4*)(a.mid_bias[j] + nbv * 16 + 4 * g);
+          for (int kc = 0; kc < NCH; ++kc) An[kc] = *(const bf16x8*)(a.mid[j + 1] + ((size_t)(kc * NB + nbv) * 64 + lane) * 16);
+          biasn = *(const f32x4*)(a.mid_bias[j + 1] + nbv * 16 + 4 * g);
+        }
+      } else if (PREB && ob0 < a.nbo) {
+#pragma unroll
+        for (int kc = 0; kc < NCHB; ++kc)
+          if (kc < a.nchb) AB[kc] = *(const bf16x8*)(a.back + ((size_t)(kc * a.nbo + ob0) * 64 + lane) * 16);
+        biasB = *(const f32x4*)(a.back_bias + ob0 * 16 + 4 * g);
+      }
       const int lo = (j + 1) * a.RW + (j + 1), hi = (a.RH - j - 2) * a.RW + (a.RW - j - 1);
       const int ng = (hi - lo + 15) >> 4;
       const bool second = j & 1;
-      for (int grp = gv; grp < ng; grp += gst) {
-        const int q = lo + grp * 16 + r;
-        const char* pin = in + q * a.PS;
-        f32x4 acc = bias;
-#pragma unroll
-        for (int kc = 0; kc < NCH; ++kc) acc = mma(A[kc], *(const bf16x8*)(pin + boff[kc]), acc);
+      auto finish = [&](int q, f32x4 acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[jj] = csp_act(acc[jj], a.act);
         if (q < hi && cch < WD) {
@@ -236,38 +296,67 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
             if (ct >= 0) lds_store4(catb + ct * a.CS + (slot0 + (j >> 1) * WD + cch) * 2, acc);
           }
         }
+      };
+      for (int grp = gv; grp < ng; grp += 2 * gst) {             // two pixel groups per step: two independent accumulator chains
+        const int qa = lo + grp * 16 + r;
+        const bool hasb = grp + gst < ng;                        // wave-uniform
+        const int qb = hasb ? qa + gst * 16 : qa;
+        const char* pa = in + qa * a.PS;
+        const char* pb = in + qb * a.PS;
+        f32x4 acca = bias, accb = bias;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+          acca = mma(A[kc], *(const bf16x8*)(pa + boff[kc]), acca);
+          accb = mma(A[kc], *(const bf16x8*)(pb + boff[kc]), accb);
+        }
+        finish(qa, acca);
+        if (hasb) finish(qb, accb);
       }
       __syncthreads();
+      if (j == 0) stamp(4);
+      if (more) {
+        if (PREN) {
+#pragma unroll
+          for (int kc = 0; kc < NCH; ++kc) A[kc] = An[kc];
+          bias = biasn;
+        } else {
+#pragma unroll
+          for (int kc = 0; kc < NCH; ++kc) A[kc] = *(const bf16x8*)(a.mid[j + 1] + ((size_t)(kc * NB + nbv) * 64 + lane) * 16);
+          bias = *(const f32x4*)(a.mid_bias[j + 1] + nbv * 16 + 4 * g);
+        }
+      }
     }
   }
+  stamp(5);
 
   // ================================================================ back: 1x1 conv over the concat, store, per-tile channel sums
   {
     const int tg = (TP + 15) >> 4;
-    int coff[CSP_NCHB_MAX];
+    int coff[NCHB];
 #pragma unroll
-    for (int kc = 0; kc < CSP_NCHB_MAX; ++kc) {
+    for (int kc = 0; kc < NCHB; ++kc) {
       const int p = kc * 4 + g;
       coff[kc] = p * 8 < a.catC ? p * 16 : 0;                   // padded piece: zero weights, finite data
     }
-    // bins of adaptive_avg_pool2d(2): the tile lies inside one of them (host-checked for MSPA)
-    const int bin = (ty0 >= a.H / 2 ? 2 : 0) + (tx0 >= a.W / 2 ? 1 : 0);
-    for (int ob = wave; ob < a.nbo; ob += CSP_NW) {
-      bf16x8 A[CSP_NCHB_MAX];
+    // few cout blocks (< 8): the waves that share a block split the tile's pixel groups; their partial sums go to separate pool slots
+    const int gst = bgst, gv = bgv;
+    for (int ob = ob0; ob < a.nbo; ob += obst) {
+      if (!PREB || ob != ob0) {
 #pragma unroll
-      for (int kc = 0; kc < CSP_NCHB_MAX; ++kc)
-        if (kc < a.nchb) A[kc] = *(const bf16x8*)(a.back + ((size_t)(kc * a.nbo + ob) * 64 + lane) * 16);
-      const f32x4 bias = *(const f32x4*)(a.back_bias + ob * 16 + 4 * g);
+        for (int kc = 0; kc < NCHB; ++kc)
+          if (kc < a.nchb) AB[kc] = *(const bf16x8*)(a.back + ((size_t)(kc * a.nbo + ob) * 64 + lane) * 16);
+        biasB = *(const f32x4*)(a.back_bias + ob * 16 + 4 * g);
+      }
       const int co = ob * 16 + 4 * g;
       const int dead = co >= a.Cout ? MGDT_OOB : 0;
       f32x4 psum = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int grp = 0; grp < tg; ++grp) {
+      for (int grp = gv; grp < tg; grp += gst) {
         const int t = grp * 16 + r;
         const char* pc = catb + t * a.CS;
-        f32x4 acc = bias;
+        f32x4 acc = biasB;
 #pragma unroll
-        for (int kc = 0; kc < CSP_NCHB_MAX; ++kc)
-          if (kc < a.nchb) acc = mma(A[kc], *(const bf16x8*)(pc + coff[kc]), acc);
+        for (int kc = 0; kc < NCHB; ++kc)
+          if (kc < a.nchb) acc = mma(AB[kc], *(const bf16x8*)(pc + coff[kc]), acc);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[jj] = (float)(bf16)csp_act(acc[jj], a.act);
         bstore4<bf16>(yrs, (uint32_t)(yoff[t] | dead) + (uint32_t)(co * 2), acc);
@@ -279,17 +368,12 @@ __global__ __launch_bounds__(CSP_THREADS) void csp_block_kernel(const CspArgs a)
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) psum[jj] += __shfl_xor(psum[jj], m, 64);
         if (r == 0 && co < a.Cout) {
-          float* pp = a.pool + (((size_t)n * tpi + trem) * a.Cout + co) * 5;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            pp[jj * 5 + 0] = psum[jj];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) pp[jj * 5 + 1 + b] = b == bin ? psum[jj] : 0.f;
-          }
+          *(f32x4*)(a.pool + (((size_t)n * tpi + trem) * gst + gv) * a.Cout + co) = psum;
         }
       }
     }
   }
+  stamp(6);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -310,6 +394,7 @@ static bool csp_geometry(int mode, int H, int W, int wd, int nbtl, int catC, siz
 }
 
 static int csp_chain_nbk(int wd) { return wd >= 16 ? wd / 16 : 1; }
+static int csp_pool_gst(int cout) { const int nbo = (cout + 15) / 16; return (nbo < CSP_NW && CSP_NW % nbo == 0) ? CSP_NW / nbo : 1; }
 
 /* supported configurations of the fused block: bf16, wd in {8,16,32,64}, n in {1,2}; MSPA: even H, W; C2f: Cin % 32 == 0, Cin <= 256 */
 extern "C" int mgdt_csp_block_supported(int mode, int cin, int cout, int wd, int nbtl, int h, int w, int dtype) {
@@ -319,7 +404,7 @@ extern "C" int mgdt_csp_block_supported(int mode, int cin, int cout, int wd, int
   if (mode == 0) {
     if (cin != 4 * wd || h % 2 || w % 2 || h < 4 || w < 4) return 0;
   } else {
-    if (cin % 32 || cin > 256 || wd < 16) return 0;
+    if (cin != 2 * wd || wd < 16) return 0;
   }
   return 1;
 }
@@ -342,7 +427,7 @@ static bool csp_pick_tile(int mode, int H, int W, int N, int wd, int nbtl, int c
       const double ratio = (double)(g.RH * g.RW) / (th * tw);
       const double fill = (double)(th * tw) / g.TPA;              // lanes of the tile's last pixel group that do work
       double cost = ratio / fill;
-      if (wgs < 512) cost *= 512.0 / wgs;                        // fewer workgroups than 2 per CU: the chip is not filled
+      if (wgs < 256) cost *= 256.0 / wgs;                        // fewer workgroups than CUs: the chip is not filled (measured: 128 big tiles beat 512 small ones at 20x20)
       if (g.lds > 76 * 1024) cost *= 1.3;                        // one workgroup per CU: nothing overlaps its barriers
       if (cost < best_cost) { best_cost = cost; *best = g; found = true; }
     }
@@ -352,8 +437,8 @@ static bool csp_pick_tile(int mode, int H, int W, int N, int wd, int nbtl, int c
 
 /* x: N x H x W x Cin view, y: N x H x W x Cout view (bf16 NHWC).  front: MSPA - the blob of mgdt_pw_chain_pack (3 convs); C2f - the
  * mgdt_conv_pack panel of cv1 (+ front_bias).  mid[2*nbtl] / mid_bias: mgdt_conv_pack panels of the bottlenecks' 3x3 convs in
- * execution order.  back / back_bias: the 1x1 conv over the concat.  pool: NULL or fp32 [N][tiles][Cout][5] in the layout of
- * mgdt_spr_pool_fwd with `tiles` splits (query the count with mgdt_csp_block_tiles). */
+ * execution order.  back / back_bias: the 1x1 conv over the concat.  pool: NULL or fp32 [N][slots][Cout] per-tile channel sums of y
+ * (slots and the tile grid: mgdt_csp_block_tiles). */
 extern "C" int mgdt_csp_block_tiles(int mode, int n, int cin, int cout, int wd, int nbtl, int h, int w, int* geom6) {
   if (!mgdt_csp_block_supported(mode, cin, cout, wd, nbtl, h, w, MGDT_BF16)) return 0;
   const int catC = (mode == 0 ? 3 : 2) * wd + nbtl * wd;
@@ -361,18 +446,21 @@ extern "C" int mgdt_csp_block_tiles(int mode, int n, int cin, int cout, int wd, 
   const size_t extra = mode == 0 ? (size_t)3 * ((nbk + 1) / 2) * nbk * 1024 + 3 * nbk * 16 * 4 : 0;
   CspGeom g;
   if (!csp_pick_tile(mode, h, w, n, wd, nbtl, catC, extra, &g)) return 0;
-  if (geom6) { geom6[0] = g.TH; geom6[1] = g.TW; geom6[2] = g.RH; geom6[3] = g.RW; geom6[4] = (int)g.lds; geom6[5] = n * g.tiles_x * g.tiles_y; }
-  return g.tiles_x * g.tiles_y;
+  if (geom6) {
+    geom6[0] = g.TH; geom6[1] = g.TW; geom6[2] = g.RH; geom6[3] = g.RW; geom6[4] = (int)g.lds; geom6[5] = n * g.tiles_x * g.tiles_y;
+    geom6[6] = g.tiles_x; geom6[7] = g.tiles_y;
+  }
+  return g.tiles_x * g.tiles_y * csp_pool_gst(cout);      // pool slots per image
 }
 
 extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* front, const float* front_bias, const void* const* mid,
                                   const float* const* mid_bias, int nbtl, int shortcut, const void* back, const float* back_bias, int wd, int act,
                                   const mgdt_view* y, float* pool, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(y) || !front || !mid || !mid_bias || !back || !back_bias) MGDT_FAIL(MGDT_BAD_ARG, "csp_block: null/empty argument");
+  if (!view_ok(x) || !view_ok(y) || (mode == 0 && !front) || !mid || !mid_bias || !back || !back_bias) MGDT_FAIL(MGDT_BAD_ARG, "csp_block: null/empty argument");
   if (!mgdt_csp_block_supported(mode, x->c, y->c, wd, nbtl, x->h, x->w, dtype))
     MGDT_FAIL(MGDT_BAD_SHAPE, "csp_block: mode=%d cin=%d cout=%d wd=%d n=%d %dx%d dtype=%d not covered", mode, x->c, y->c, wd, nbtl, x->h, x->w, dtype);
-  if (mode == 1 && !front_bias) MGDT_FAIL(MGDT_BAD_ARG, "csp_block: C2f front needs its bias");
   if (x->n != y->n || x->h != y->h || x->w != y->w) MGDT_FAIL(MGDT_BAD_SHAPE, "csp_block: x and y must have one spatial size");
+  if (act != MGDT_ACT_SILU) MGDT_FAIL(MGDT_BAD_ARG, "csp_block: activation %d (only SiLU, the blocks' default, is built)", act);
   for (int j = 0; j < 2 * nbtl; ++j)
     if (!mid[j] || !mid_bias[j]) MGDT_FAIL(MGDT_BAD_ARG, "csp_block: missing conv panel %d", j);
   CspArgs a;
@@ -385,7 +473,7 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
     *p = (const char*)v->p; *sn = (int)(v->sn * sz); *sh = (int)(v->sh * sz); *sw = (int)(v->sw * sz); *bytes = (uint32_t)ext;
   };
   const char* yp = nullptr;
-  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes, mode == 0 ? 4 : 8);
+  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes, 4);
   bind(y, &yp, &a.ysn, &a.ysh, &a.ysw, &a.y_bytes, 4);
   if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "csp_block: views must be aligned NHWC (sc == 1) and span < 2 GiB");
   a.y = (char*)yp;
@@ -394,9 +482,7 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   a.back = (const char*)back; a.back_bias = back_bias; a.pool = pool;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = y->c; a.wd = wd; a.nbtl = nbtl; a.shortcut = shortcut; a.act = act;
   a.catC = (mode == 0 ? 3 : 2) * wd + nbtl * wd;
-  a.nchb = (a.catC / 8 + 3) / 4; a.nbo = (a.Cout + 15) / 16;
-  a.front_nch = x->c / 32; a.front_nb = mode == 1 ? 2 * wd / 16 : 1;
-  if (mode == 1 && (CSP_NW % a.front_nb || a.front_nch > CSP_FRONT_NCH_MAX)) MGDT_FAIL(MGDT_BAD_SHAPE, "csp_block: C2f front %d -> %d not covered", x->c, 2 * wd);
+  a.nchb = (a.catC / 8 + 3) / 4; a.nbo = (a.Cout + 15) / 16; a.pool_gst = csp_pool_gst(a.Cout);
   const int nbk = csp_chain_nbk(wd);
   a.chain_words = mode == 0 ? 3 * ((nbk + 1) / 2) * nbk * 64 : 0;
   const size_t extra = mode == 0 ? (size_t)a.chain_words * 16 + 3 * nbk * 16 * 4 : 0;
@@ -408,6 +494,14 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   a.per_xcd = cdiv(a.total_tiles, 8);
   const int grid = 8 * a.per_xcd;
   hipStream_t st = (hipStream_t)s;
+  static unsigned long long* dbgbuf = nullptr;            // MGDT_CSP_DBG=1: per-workgroup phase stamps, printed after the launch (debug only)
+  static size_t dbgcap = 0;
+  if (getenv("MGDT_CSP_DBG") && dbgcap < (size_t)a.total_tiles * 8) {
+    if (dbgbuf) (void)hipFree(dbgbuf);
+    dbgcap = (size_t)a.total_tiles * 8;
+    (void)hipMalloc((void**)&dbgbuf, dbgcap * 8);
+  }
+  a.dbg = getenv("MGDT_CSP_DBG") ? dbgbuf : nullptr;
 #define CSP_LAUNCH(WDV, MODEV)                                                                                              \
   do {                                                                                                                      \
     static bool attr = false;                                                                                               \
@@ -425,5 +519,20 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   }
 #undef CSP_LAUNCH
   MGDT_CHECK_LAUNCH("csp_block_fwd");
+  if (a.dbg) {
+    std::vector<unsigned long long> h((size_t)a.total_tiles * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < a.total_tiles; ++i) {
+      t0 = std::min(t0, h[(size_t)i * 8]); t1 = std::max(t1, h[(size_t)i * 8 + 6]);
+      for (int k = 0; k < 6; ++k) ph[k] += (double)(h[(size_t)i * 8 + k + 1] - h[(size_t)i * 8 + k]);
+    }
+    const double nw = a.total_tiles;
+    fprintf(stderr, "csp_block mode %d wd %d n %d %dx%d tile %dx%d (%d wgs, lds %zu): span %.1f us; avg per WG (us): tables %.2f front %.2f sync %.2f conv0 %.2f "
+                    "other convs %.2f back %.2f\n", mode, wd, nbtl, a.H, a.W, g.TH, g.TW, a.total_tiles, g.lds, (t1 - t0) * 0.01, ph[0] / nw * 0.01,
+            ph[1] / nw * 0.01, ph[2] / nw * 0.01, ph[3] / nw * 0.01, ph[4] / nw * 0.01, ph[5] / nw * 0.01);
+  }
   return MGDT_OK;
 }

@@ -260,7 +260,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
                                                              const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh,
-                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit) {
+                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit, int tiles_x, int tiles_y) {
   extern __shared__ float sm[];
   const int n = blockIdx.y, cw = C / G, hid = cw / 4;
   float* pooled = sm;               // [C][5] means
@@ -269,12 +269,48 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   float* att = obuf + C;            // [C] softmax over groups
   const int hs1 = bin_start(1, H, 2), he0 = bin_end(0, H, 2), ws1 = bin_start(1, W, 2), we0 = bin_end(0, W, 2);
   const float cnt[5] = {(float)H * W, (float)he0 * we0, (float)he0 * (W - ws1), (float)(H - hs1) * we0, (float)(H - hs1) * (W - ws1)};
-  for (int i = threadIdx.x; i < C * 5; i += 256) {
-    float sum = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) sum += partial[((long)n * nsplit + sp) * C * 5 + i];
-    pooled[i] = sum / cnt[i % 5];
+  if (tiles_x > 0) {
+    // per-tile sums written by mgdt_csp_block_fwd: partial[n][slot][c], slot = tile * gst + k, tile = ty * tiles_x + tx lies inside ONE pooling
+    // bin.  256 threads read coalesced rows of C floats with many loads in flight (a serial walk over hundreds of slots per value is
+    // latency-bound: it cost more than the block kernel itself), then the threads that share a channel are summed in a fixed order.
+    __shared__ float red[5 * 256];
+    const int gst = nsplit / (tiles_x * tiles_y);
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int lanes_c = min(C - c0, 256);                     // channels handled in this pass
+      const int ph = 256 / lanes_c;                             // threads per channel (C is a multiple of 4, <= 256 typical)
+      const int c = c0 + threadIdx.x % lanes_c, sp0 = threadIdx.x / lanes_c;
+      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      if (sp0 < ph) {
+        for (int sp = sp0; sp < nsplit; sp += ph) {
+          const float v = partial[((long)n * nsplit + sp) * C + c];
+          const int tile = sp / gst, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+          const int bin = (2 * ty >= tiles_y ? 2 : 0) + (2 * tx >= tiles_x ? 1 : 0);
+          acc[0] += v;
+          acc[1] += bin == 0 ? v : 0.f;
+          acc[2] += bin == 1 ? v : 0.f;
+          acc[3] += bin == 2 ? v : 0.f;
+          acc[4] += bin == 3 ? v : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[k * 256 + threadIdx.x] = acc[k];
+      __syncthreads();
+      for (int o = threadIdx.x; o < lanes_c * 5; o += 256) {
+        const int cc = o % lanes_c, k = o / lanes_c;
+        float sum = 0.f;
+        for (int p = 0; p < ph; ++p) sum += red[k * 256 + p * lanes_c + cc];
+        pooled[(c0 + cc) * 5 + k] = sum / cnt[k];
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = threadIdx.x; i < C * 5; i += 256) {
+      float sum = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) sum += partial[((long)n * nsplit + sp) * C * 5 + i];
+      pooled[i] = sum / cnt[i % 5];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int o = threadIdx.x; o < G * hid; o += 256) {   // fc1 + relu (spr_module.py:21-23), as in spr_attn_kernel
     int gi = o / hid, hj = o % hid;
     const float* wr = w1 + (long)hj * 5 * cw;
@@ -332,9 +368,11 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   }
 }
 
-extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
+extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tiles_x, int tiles_y, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
                                        const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
   if (nsplit <= 0) nsplit = SPR_SPLITS;
+  if (tiles_x > 0 && (tiles_y <= 0 || nsplit % (tiles_x * tiles_y) || tiles_x % 2 || tiles_y % 2 || x->h % 2 || x->w % 2))
+    MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: per-tile sums need an even tile grid over an even map (nsplit=%d tiles %dx%d)", nsplit, tiles_y, tiles_x);
   if (!pooled || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "spr_attn_scale: null/empty argument");
   const int c = x->c;
   if (groups < 1 || c % groups || (c / groups) % 4 || c > 4096) MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: c=%d groups=%d", c, groups);
@@ -348,7 +386,7 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, const fl
     const int K = (int)std::max<long>(1, std::min<long>(64, vecs / per_wg));
     spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
                                                                               x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
-                                                                              make_fastdiv((uint32_t)x->w), nsplit);
+                                                                              make_fastdiv((uint32_t)x->w), nsplit, tiles_x, tiles_y);
   });
   MGDT_CHECK_LAUNCH("spr_attn_scale_fwd");
   return MGDT_OK;

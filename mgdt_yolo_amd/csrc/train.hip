@@ -1,6 +1,6 @@
 // Training-side kernels of the detection path: BatchNorm2d in training mode (batch statistics, running-stat update,
 // fused activation and residual adds), its backward, convolution dgrad / wgrad / bias-grad, and the adjoints of the pooling /
-// resampling ops.  First-cut versions: correct, deterministic (fixed-order reductions, no float atomics except max-pool
+// resampling ops.  First-cut versions: correct, deterministic (fixed-order reductions, no float atomics; max-pool
 // routing), channel-vectorised; the MFMA treatment the forward convolution got is the next step for dgrad(stride 2) / wgrad.
 // Reference semantics: nn.BatchNorm2d(eps 1e-3, momentum 0.03) as set by initialize_weights (yolo/utils/torch_utils.py:254-256):
 // normalise with the biased batch variance, update running_var with the unbiased one.
@@ -453,7 +453,10 @@ extern "C" int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_v
   return MGDT_OK;
 }
 
-// MaxPool2d(5,1,2) backward: gx[argmax window(o)] += gy[o]; argmax = first maximum in (ky, kx) scan order (ATen semantics).
+// MaxPool2d(5,1,2) backward as a GATHER (deterministic, no float atomics): gx[i] = sum of gy[o] over the outputs o whose window's
+// argmax is i; argmax = ATen's scan: first maximum in (ky, kx) order, a NaN replaces whatever was found before it.  Every window that
+// contains i is re-scanned exactly as the forward scanned it (25 x 25 cached loads per element; the P5 map is tiny), and the
+// contributions are added in (oy, ox) order, so two runs give the same bits.
 template <typename T>
 __global__ void maxpool5_bwd_kernel(const mgdt_view x, const mgdt_view gy, float* gx_f32) {
   long total = (long)x.n * x.h * x.w * x.c;
@@ -464,24 +467,34 @@ __global__ void maxpool5_bwd_kernel(const mgdt_view x, const mgdt_view gy, float
     t /= x.w;
     int h = (int)(t % x.h);
     long n = t / x.h;
-    float best = -INFINITY;
-    int by = h, bx = w;
-    for (int dy = -2; dy <= 2; ++dy) {
-      int yy = h + dy;
-      if ((unsigned)yy >= (unsigned)x.h) continue;
-      for (int dx = -2; dx <= 2; ++dx) {
-        int xx = w + dx;
-        if ((unsigned)xx >= (unsigned)x.w) continue;
-        float v = (float)((const T*)x.p)[n * x.sn + yy * x.sh + xx * x.sw + c];
-        if (v > best || isnan(v)) { best = v; by = yy; bx = xx; }
+    const T* xb = (const T*)x.p + n * x.sn + c;
+    const T* gb = (const T*)gy.p + n * gy.sn + c;
+    const float mine = (float)xb[h * x.sh + w * x.sw];
+    float acc = 0.f;
+    for (int oy = h - 2; oy <= h + 2; ++oy) {
+      if ((unsigned)oy >= (unsigned)x.h) continue;
+      for (int ox = w - 2; ox <= w + 2; ++ox) {
+        if ((unsigned)ox >= (unsigned)x.w) continue;
+        float best = -INFINITY;
+        int by = oy, bx = ox;
+        for (int dy = -2; dy <= 2; ++dy) {
+          int yy = oy + dy;
+          if ((unsigned)yy >= (unsigned)x.h) continue;
+          for (int dx = -2; dx <= 2; ++dx) {
+            int xx = ox + dx;
+            if ((unsigned)xx >= (unsigned)x.w) continue;
+            float v = (yy == h && xx == w) ? mine : (float)xb[yy * x.sh + xx * x.sw];
+            if (v > best || isnan(v)) { best = v; by = yy; bx = xx; }
+          }
+        }
+        if (by == h && bx == w) acc += (float)gb[oy * gy.sh + ox * gy.sw];
       }
     }
-    float g = (float)((const T*)gy.p)[n * gy.sn + h * gy.sh + w * gy.sw + c];
-    atomicAdd(gx_f32 + ((n * x.h + by) * x.w + bx) * x.c + c, g);
+    gx_f32[((n * x.h + h) * x.w + w) * x.c + c] = acc;
   }
 }
 
-// gx_f32: dense fp32 [n][h][w][c] accumulator, zeroed by the caller (hipMemsetAsync) - the P5 map is tiny.
+// gx_f32: dense fp32 [n][h][w][c], every element written (no need to zero it).
 extern "C" int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(gy) || !gx_f32) MGDT_FAIL(MGDT_BAD_ARG, "maxpool5_bwd: null/empty argument");
   if (x->sc != 1 || gy->sc != 1 || x->n != gy->n || x->h != gy->h || x->w != gy->w || x->c != gy->c) MGDT_FAIL(MGDT_BAD_SHAPE, "maxpool5_bwd: matching NHWC views");

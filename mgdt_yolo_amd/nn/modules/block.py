@@ -26,6 +26,8 @@ def _plain_block(first, last, bottlenecks):
         a0 = act_code(first.act)
     except RuntimeError:
         return False
+    if a0 != ops.ACT_SILU:            # the fused block kernel is built for the blocks' default activation
+        return False
     if not (conv_ok(first, 1) and conv_ok(last, 1)) or len(bottlenecks) == 0:
         return False
     return all(isinstance(m, Bottleneck) and conv_ok(m.cv1, 3) and conv_ok(m.cv2, 3) and m.add == bottlenecks[0].add
@@ -87,12 +89,14 @@ class C2f(HipModule):
         c, n = self.c, len(self.m)
         train = self.training and hasattr(self.cv1, 'bn')
         dt = self.cv1.out_dtype(x)
-        if not train and _plain_block(self.cv1, self.cv2, self.m) and ops.csp_block_supported(ops.CSP_C2F, x, self.cv2.conv.out_channels, c, n, dt):
-            # the whole block in one launch: cv1, the bottleneck chain on LDS-resident tiles, cv2 over the concat (mgdt_csp_block_fwd)
-            mids = [pk for m in self.m for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
-            pk1 = self.cv1.packed(dt, False)
-            return ops.csp_block(ops.CSP_C2F, x, pk1.w, pk1.bias, mids, self.m[0].add, self.cv2.packed(dt, False), c, act_code(self.cv1.act),
-                                 self.cv2.conv.out_channels, False)[0]
+        if not train and x.dtype == dt and _plain_block(self.cv1, self.cv2, self.m):
+            y01 = ops.new_act(b, 2 * c, h, w, dt, x.device)
+            if ops.csp_block_supported(ops.CSP_C2F, y01, self.cv2.conv.out_channels, c, n, dt):
+                # two launches: cv1 (a wide streaming 1x1 GEMM), then the bottleneck chain on LDS-resident tiles + cv2 over the concat
+                self.cv1.run(x, out=y01)
+                mids = [pk for m in self.m for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
+                return ops.csp_block(ops.CSP_C2F, y01, None, None, mids, self.m[0].add, self.cv2.packed(dt, False), c, act_code(self.cv1.act),
+                                     self.cv2.conv.out_channels, False)[0]
         cat = ops.new_act(b, (2 + n) * c, h, w, dt, x.device)
         (self.cv1.train_fwd if train else self.cv1.run)(x, out=cat[:, :2 * c])
         for j, m in enumerate(self.m):
@@ -146,9 +150,9 @@ class MSPA_C2f(HipModule):
                 and ops.csp_block_supported(ops.CSP_MSPA, x, self.convs[3].conv.out_channels, wd, n, dt)):
             # one launch for the block (mgdt_csp_block_fwd) + one for attention MLP and scaling; the pooled sums come out of the block kernel
             mids = [pk for m in self.bottleneck for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
-            out, pool, tiles = ops.csp_block(ops.CSP_MSPA, x, self._packed_chain(dt).blob, None, mids, self.bottleneck[0].add, self.convs[3].packed(dt, False),
-                                             wd, act_code(self.convs[0].act), self.convs[3].conv.out_channels, True)
-            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, part=pool, nsplit=tiles)
+            out, pool, slots, tiles = ops.csp_block(ops.CSP_MSPA, x, self._packed_chain(dt).blob, None, mids, self.bottleneck[0].add,
+                                                    self.convs[3].packed(dt, False), wd, act_code(self.convs[0].act), self.convs[3].conv.out_channels, True)
+            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, part=pool, nsplit=slots, tiles=tiles)
         cat = ops.new_act(b, (s - 1 + n) * wd, h, w, dt, x.device)
         # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
         if not train and s == 4 and ops.pw_chain_supported(wd, cat.dtype) and x.dtype == cat.dtype and self._chain_ok():

