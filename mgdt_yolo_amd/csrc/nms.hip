@@ -94,74 +94,80 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     return akeys[i];
   };
   unsigned long long T0 = wall_clock64();
+  unsigned long long Tsel = 0, Tsort = 0, Tgreedy = 0;
+  // every pass over the candidates (count, the radix-select passes, the compactions) re-reads the same keys: when they fit, a thread keeps
+  // its share (flat indices tid, tid + 1024, ...) in registers for the whole kernel
+  constexpr int KPT = 8;
+  const bool cached = total <= (long)KPT * NMS_THREADS;
+  u64 mykey[KPT];
+#pragma unroll
+  for (int t = 0; t < KPT; ++t) {
+    const long i = (long)t * NMS_THREADS + tid;
+    mykey[t] = (cached && i < total) ? key_at(i) : KEY_NONE;
+  }
+  auto for_each_key = [&](auto fn) __attribute__((always_inline)) {     // fn(key) for every candidate key of this thread (KEY_NONE included)
+    if (cached) {
+#pragma unroll
+      for (int t = 0; t < KPT; ++t) fn(mykey[t]);
+    } else {
+      for (long i = tid; i < total; i += NMS_THREADS) fn(key_at(i));
+    }
+  };
   // ---- count candidates
   if (tid == 0) { s_cnt = 0; s_sel = 0; }
   __syncthreads();
   {
     unsigned local = 0;
-    for (long i = tid; i < total; i += NMS_THREADS) local += key_at(i) != KEY_NONE;
+    for_each_key([&](u64 k) { local += k != KEY_NONE; });
     atomicAdd(&s_cnt, local);
   }
   __syncthreads();
   const unsigned ncand = s_cnt;
-  unsigned K = ncand < (unsigned)a.max_nms ? ncand : (unsigned)a.max_nms;
+  const unsigned K = ncand < (unsigned)a.max_nms ? ncand : (unsigned)a.max_nms;
 
-  // ---- threshold key: the K-th smallest key (MSD radix select, 8 bits per pass), only when truncating
-  u64 kth = KEY_NONE - 1;   // select everything valid
-  if (ncand > K) {
+  // R-th smallest key (1-based rank R <= ncand): MSD radix select, 8 bits per pass.  Keys are unique (candidate id in the low word),
+  // so exactly R keys are <= the result.
+  __shared__ unsigned s_exact;
+  auto select_rank = [&](unsigned R) -> u64 {
     u64 prefix = 0;
-    unsigned need = K;      // rank (1-based) of the wanted key among keys matching the prefix
+    unsigned need = R;
     for (int shift = 56; shift >= 0; shift -= 8) {
       for (int i = tid; i < 256; i += NMS_THREADS) hist[i] = 0;
       __syncthreads();
       const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-      for (long i = tid; i < total; i += NMS_THREADS) {
-        u64 k = key_at(i);
-        if (k != KEY_NONE && (k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
-      }
+      for_each_key([&](u64 k) { if (k != KEY_NONE && (k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u); });
       __syncthreads();
-      if (tid == 0) {
-        unsigned run = 0, b = 0;
-        for (; b < 256; ++b) {
-          if (run + hist[b] >= need) break;
-          run += hist[b];
+      if (tid < 64) {      // wave 0: first bin b with (keys in bins < b) + hist[b] >= need, by a 64-lane prefix scan over 4 bins per lane
+        const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const unsigned sum = h0 + h1 + h2 + h3;
+        unsigned incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const unsigned t = __shfl_up(incl, d, 64);
+          if (tid >= d) incl += t;
         }
-        s_prefix = prefix | ((u64)b << shift);
-        s_sel = need - run;
+        const unsigned excl = incl - sum;
+        if (excl < need && need <= incl) {               // exactly one lane
+          unsigned run = excl, b = 4 * tid, hb = h0;
+          if (run + h0 < need) { run += h0; ++b; hb = h1; if (run + h1 < need) { run += h1; ++b; hb = h2; if (run + h2 < need) { run += h2; ++b; hb = h3; } } }
+          s_prefix = prefix | ((u64)b << shift);
+          s_sel = need - run;
+          s_exact = (need - run == hb) ? 1u : 0u;          // the whole bin is wanted: every lower bit may be 1
+        }
       }
       __syncthreads();
       prefix = s_prefix;
       need = s_sel;
+      const bool exact = s_exact != 0;
       __syncthreads();
+      if (exact) return shift ? (prefix | ((1ull << shift) - 1ull)) : prefix;
     }
-    kth = prefix;   // keys are unique (candidate id in the low word): exactly K keys are <= kth
-  }
+    return prefix;
+  };
 
-  unsigned long long T1 = wall_clock64();
-  // ---- compact the selected keys into the sort buffer (unordered), pad to a power of two
-  unsigned np2 = 1;
-  while (np2 < K) np2 <<= 1;
-  u64* sbuf = (np2 <= NMS_LDS_KEYS) ? (u64*)smem : gbuf;
-  if (tid == 0) s_sel = 0;
-  __syncthreads();
-  for (long base = 0; base < total; base += NMS_THREADS) {   // wave-aggregated: one LDS atomic per wave, not per key
-    const long i = base + tid;
-    const u64 k = i < total ? key_at(i) : KEY_NONE;
-    const bool sel = k != KEY_NONE && k <= kth;
-    const u64 m = __ballot(sel);
-    unsigned wbase = 0;
-    if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_sel, (unsigned)__popcll(m));
-    wbase = __shfl(wbase, 0);
-    if (sel) sbuf[wbase + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = k;
-  }
-  for (unsigned i = K + tid; i < np2; i += NMS_THREADS) sbuf[i] = KEY_NONE;
-  __syncthreads();
-
-  unsigned long long T2 = wall_clock64();
-  // ---- bitonic sort ascending (== descending score, ascending candidate id).  Every thread owns np2/2/1024 disjoint pairs per
-  // pass and issues all its loads before the compare-exchanges (independent LDS accesses in flight instead of a dependent
-  // chain); the LDS case is a separate instantiation so the compiler emits ds_read/ds_write_b64, not flat accesses.
-  auto bitonic = [&](auto* buf) __attribute__((always_inline)) {
+  // bitonic sort ascending (== descending score, ascending candidate id).  Every thread owns disjoint pairs per pass and issues all its
+  // loads before the compare-exchanges; the LDS case is a separate instantiation so the compiler emits ds_read/ds_write_b64.
+  auto bitonic = [&](auto* buf, unsigned np2) __attribute__((always_inline)) {
     const unsigned npairs = np2 >> 1;
     const unsigned blk = np2 / (NMS_THREADS / 64);          // contiguous elements owned by one wave in the wave-local passes
     const bool local_ok = blk >= 128;
@@ -215,88 +221,173 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       }
     }
   };
-  if (np2 <= NMS_LDS_KEYS) bitonic((u64*)smem);
-  else bitonic(gbuf);
 
-  unsigned long long T3 = wall_clock64();
-  // ---- greedy suppression, all 16 waves: 1024 sorted candidates per round.
-  //   phase A (parallel): every lane tests its candidate against the boxes kept in earlier rounds (LDS broadcast reads);
-  //   phase B (wave after wave, in score order): a wave first tests against the boxes kept earlier in THIS round, then
-  //   resolves its 64 candidates with ballot + shuffles, appends the survivors to the kept list and writes the output rows.
+  // ---- greedy state
   float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
-  unsigned* kidx = (unsigned*)(kb + 5 * a.max_det);                  // sorted position of each kept box
-  __shared__ int s_nkept, s_turn;
-  if (tid == 0) { s_nkept = 0; s_turn = 0; }
+  u64* kkey = (u64*)(kb + 5 * a.max_det + (a.max_det & 1));          // key of each kept box (8-byte aligned)
+  __shared__ int s_nkept;
+  __shared__ unsigned s_sup[2], s_sb[64][2];
+  if (tid == 0) { s_nkept = 0; s_sup[0] = 0; s_sup[1] = 0; }
+  if (tid < 64) { s_sb[tid][0] = 0; s_sb[tid][1] = 0; }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int md = a.max_det;
-  auto suppressed_by = [&](int k, float bx1, float by1, float bx2, float by2, float area) -> bool {
-    float xx1 = fmaxf(kb[k], bx1), yy1 = fmaxf(kb[md + k], by1);
-    float xx2 = fminf(kb[2 * md + k], bx2), yy2 = fminf(kb[3 * md + k], by2);
-    float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-    float inter = iw * ih;
-    float ovr = inter / (kb[4 * md + k] + area - inter);
-    return ovr > a.iou;
+  // IoU test of the torchvision CPU kernel in IEEE fp32 (no contraction).  Boxes that do not intersect (almost all pairs) skip the division:
+  // then inter == 0 and the quotient is 0, -0 or NaN, none of which exceeds iou_thres >= 0 - the same answer, bit for bit.
+  auto overlaps = [&](float kx1, float ky1, float kx2, float ky2, float karea, float bx1, float by1, float bx2, float by2, float area) -> bool {
+    const float iw = fminf(kx2, bx2) - fmaxf(kx1, bx1), ih = fminf(ky2, by2) - fmaxf(ky1, by1);
+    if (!(iw > 0.f && ih > 0.f)) return false;
+    const float inter = iw * ih;
+    return inter / (karea + area - inter) > a.iou;
   };
-  for (unsigned base = 0; base < K; base += NMS_THREADS) {
-    const int nk0 = s_nkept;            // kept before this round
-    __syncthreads();                    // everyone has read it before wave 0's turn may change it -> uniform
-    if (nk0 >= md) break;
-    unsigned idx = base + tid;
-    bool valid = idx < K;
-    u64 key = valid ? sbuf[idx] : KEY_NONE;
-    unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
-    int an = valid ? (int)(cand / (unsigned)a.nc) : 0, cls = valid ? (int)(cand % (unsigned)a.nc) : 0;
-    float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
-    float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
-    float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
-    float bx1 = x1 + off, by1 = y1 + off, bx2 = x2 + off, by2 = y2 + off;
-    float area = (bx2 - bx1) * (by2 - by1);
-    bool alive = valid;
-    for (int k = 0; k < nk0; ++k)
-      if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
-    // phase B, pipelined: the waves take their turn in score order, but while a wave waits for its turn it already tests its
-    // candidates against the boxes the earlier waves publish (kept list + count in LDS), so only the 64-lane resolution itself
-    // is serial.  s_turn = first wave of this round that has not finished; a wave that sees s_turn == its index has, by then,
-    // seen every box kept before it (the count is read after the turn).
-    {
-      int seen = nk0;
-      for (;;) {
-        const int turn = __hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int nk = __hip_atomic_load(&s_nkept, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int k = seen; k < nk; ++k)
-          if (suppressed_by(k, bx1, by1, bx2, by2, area)) alive = false;
-        seen = nk;
-        if (turn == wave) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      int nkept = seen;
-      u64 mask = __ballot(alive);
-      while (mask && nkept < md) {
-        int i = __ffsll((long long)mask) - 1;   // earliest surviving lane becomes a kept box
-        if (lane == i) {
-          kb[nkept] = bx1; kb[md + nkept] = by1; kb[2 * md + nkept] = bx2; kb[3 * md + nkept] = by2; kb[4 * md + nkept] = area;
-          kidx[nkept] = idx;                    // its output row is written after the scan, in parallel
-          alive = false;
+  auto suppressed_by = [&](int k, float bx1, float by1, float bx2, float by2, float area) -> bool {
+    return overlaps(kb[k], kb[md + k], kb[2 * md + k], kb[3 * md + k], kb[4 * md + k], bx1, by1, bx2, by2, area);
+  };
+
+  // ---- segments: the scan stops at max_det kept boxes, which usually happens within the first few hundred candidates, so only the best
+  // `seg` keys are selected and sorted first (1024, then 4x more, ...) instead of all of them
+  unsigned done = 0, seg = 1024;
+  u64 lo_key = 0;
+  while (done < K) {
+    if (s_nkept >= md) break;                                // uniform: read after a barrier (end of the previous segment)
+    unsigned long long Ta = wall_clock64();
+    const unsigned R = (K - done <= seg + seg / 2) ? K : done + seg;      // do not leave a small tail for another pass
+    const u64 hi_key = (R == ncand) ? KEY_NONE - 1 : select_rank(R);
+    const unsigned cnt = R - done;
+    unsigned np2 = 1;
+    while (np2 < cnt) np2 <<= 1;
+    u64* sbuf = (np2 <= NMS_LDS_KEYS) ? (u64*)smem : gbuf;
+    if (tid == 0) s_sel = 0;
+    __syncthreads();
+    auto put = [&](u64 k) __attribute__((always_inline)) {      // wave-aggregated: one LDS atomic per wave, not per key
+      const bool sel = k != KEY_NONE && k <= hi_key && (done == 0 || k > lo_key);
+      const u64 m = __ballot(sel);
+      unsigned wbase = 0;
+      if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_sel, (unsigned)__popcll(m));
+      wbase = __shfl(wbase, 0);
+      if (sel) sbuf[wbase + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = k;
+    };
+    if (cached) {
+#pragma unroll
+      for (int t = 0; t < KPT; ++t) put(mykey[t]);
+    } else {
+      for (long base = 0; base < total; base += NMS_THREADS) put(base + tid < total ? key_at(base + tid) : KEY_NONE);   // uniform trip count (ballots)
+    }
+    for (unsigned i = cnt + tid; i < (np2 < NMS_THREADS ? (unsigned)NMS_THREADS : np2); i += NMS_THREADS) sbuf[i] = KEY_NONE;
+    __syncthreads();
+    unsigned long long Tb = wall_clock64();
+    if (np2 <= NMS_THREADS) {
+      // one key per thread: the 45 passes with partner distance < 64 are register shuffles inside a wave, the 10 cross-wave ones go through
+      // two alternating LDS buffers (one barrier each)
+      u64* sb2 = (u64*)smem + NMS_THREADS;
+      u64 kv = ((u64*)smem)[tid];
+      int pb = 0;
+      for (unsigned k2 = 2; k2 <= NMS_THREADS; k2 <<= 1) {
+        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+          u64 other;
+          if (j < 64) {
+            const unsigned lo32 = __shfl_xor((unsigned)kv, (int)j, 64), hi32 = __shfl_xor((unsigned)(kv >> 32), (int)j, 64);
+            other = ((u64)hi32 << 32) | lo32;
+          } else {
+            u64* wb = pb ? sb2 : (u64*)smem;
+            wb[tid] = kv;
+            __syncthreads();
+            other = wb[tid ^ j];
+            pb ^= 1;
+          }
+          const bool up = (tid & k2) == 0, lower = (tid & j) == 0;
+          const bool take_min = lower == up;
+          kv = take_min ? (kv < other ? kv : other) : (kv > other ? kv : other);
         }
-        // lane i's LDS write must be ordered before the other lanes' reads: wavefront-scope fence for the compiler, the LDS pipe
-        // itself completes a wave's accesses in order; then a broadcast read replaces five shuffles
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (alive && lane > i && suppressed_by(nkept, bx1, by1, bx2, by2, area)) alive = false;
-        ++nkept;
-        if (lane == 0) __hip_atomic_store(&s_nkept, nkept, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // later waves may test it now
-        mask = __ballot(alive);
       }
-      if (lane == 0) __hip_atomic_store(&s_turn, wave + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();                                         // the last cross-wave reads are done before smem[] is rewritten
+      ((u64*)smem)[tid] = kv;
+      __syncthreads();
+    } else if (np2 <= NMS_LDS_KEYS) bitonic((u64*)smem, np2);
+    else bitonic(gbuf, np2);
+    unsigned long long Tc = wall_clock64();
+
+    // ---- greedy suppression over this segment, 64 sorted candidates per step, the whole workgroup on each step:
+    //   lane = candidate, wave s tests it against the kept boxes k = s, s+16, ... (a kept box is one broadcast LDS read for the wave) and
+    //   against the chunk's own candidates 4s .. 4s+3 (bit j of sb[c]: the earlier candidate j suppresses c); the waves' verdicts are
+    //   OR-ed in LDS.  Then wave 0 walks the 64 candidates in score order with scalar bit operations only (no IoU arithmetic in the
+    //   serial part) and appends the survivors to the kept list.  The next chunk's boxes are loaded while this one is resolved.
+    struct Cand { u64 key; float bx1, by1, bx2, by2, area; bool valid; };
+    auto load_cand = [&](unsigned idx) -> Cand {
+      Cand c;
+      c.valid = idx < cnt;
+      c.key = c.valid ? sbuf[idx] : KEY_NONE;
+      const unsigned cand = (unsigned)(c.key & 0xFFFFFFFFu);
+      const int an = c.valid ? (int)(cand / (unsigned)a.nc) : 0, cls = c.valid ? (int)(cand % (unsigned)a.nc) : 0;
+      const float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
+      const float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
+      const float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
+      c.bx1 = x1 + off; c.by1 = y1 + off; c.bx2 = x2 + off; c.by2 = y2 + off;
+      c.area = (c.bx2 - c.bx1) * (c.by2 - c.by1);
+      return c;
+    };
+    Cand cur = load_cand((unsigned)lane);
+    for (unsigned base = 0; base < cnt; base += 64) {
+      const int nk = s_nkept;             // uniform: written by wave 0 before the barrier that ended the previous step
+      if (nk >= md) break;
+      Cand nxt = load_cand(base + 64 + (unsigned)lane);      // in flight during this step
+      bool sup = false;
+      for (int k = wave; k < nk; k += NMS_THREADS / 64)
+        if (suppressed_by(k, cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) sup = true;
+      unsigned sb_lo = 0, sb_hi = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = wave * 4 + t;                          // uniform
+        const float jx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx1), j));
+        const float jy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by1), j));
+        const float jx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx2), j));
+        const float jy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by2), j));
+        const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.area), j));
+        // kept box = the earlier candidate j, tested box = this lane's: the argument order of the serial scan
+        if (j < lane && overlaps(jx1, jy1, jx2, jy2, jar, cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) {
+          if (j < 32) sb_lo |= 1u << j; else sb_hi |= 1u << (j - 32);
+        }
+      }
+      if (sb_lo) atomicOr(&s_sb[lane][0], sb_lo);
+      if (sb_hi) atomicOr(&s_sb[lane][1], sb_hi);
+      {
+        const u64 m = __ballot(sup);
+        if (lane == 0 && m) { atomicOr(&s_sup[0], (unsigned)m); atomicOr(&s_sup[1], (unsigned)(m >> 32)); }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const u64 supm = ((u64)s_sup[1] << 32) | s_sup[0];
+        const unsigned mlo = s_sb[lane][0], mhi = s_sb[lane][1];      // earlier candidates of the chunk that suppress this one
+        u64 am = __ballot(cur.valid) & ~supm, keep = 0;
+        int room = md - nk;
+        while (am && room > 0) {                               // candidate i (in score order) survives iff no kept earlier one suppresses it
+          const int i = __ffsll((long long)am) - 1;
+          am &= ~(1ull << i);
+          const u64 by = ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mlo, i);
+          if ((by & keep) == 0) { keep |= 1ull << i; --room; }
+        }
+        if ((keep >> lane) & 1ull) {
+          const int slot = nk + __popcll(keep & ((1ull << lane) - 1ull));
+          kb[slot] = cur.bx1; kb[md + slot] = cur.by1; kb[2 * md + slot] = cur.bx2; kb[3 * md + slot] = cur.by2; kb[4 * md + slot] = cur.area;
+          kkey[slot] = cur.key;
+        }
+        s_sb[lane][0] = 0; s_sb[lane][1] = 0;
+        if (lane == 0) { s_sup[0] = 0; s_sup[1] = 0; s_nkept = nk + (int)__popcll(keep); }
+      }
+      __syncthreads();
+      cur = nxt;
     }
     __syncthreads();
-    if (tid == 0) s_turn = 0;
+    unsigned long long Td = wall_clock64();
+    Tsel += Tb - Ta; Tsort += Tc - Tb; Tgreedy += Td - Tc;
+    done = R;
+    lo_key = hi_key;
+    seg *= 4;
   }
+  __syncthreads();
   // output rows (x1,y1,x2,y2,conf,cls) + anchor index of the kept boxes, one thread per row
   for (int t = tid; t < s_nkept; t += NMS_THREADS) {
-    const u64 key = sbuf[kidx[t]];
+    const u64 key = kkey[t];
     const unsigned cand = (unsigned)(key & 0xFFFFFFFFu);
     const int an = (int)(cand / (unsigned)a.nc), cls = (int)(cand % (unsigned)a.nc);
     const float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
@@ -307,7 +398,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     a.kept_anchor[(long)img * md + t] = an;
   }
   if (tid == 0) a.counts[img] = s_nkept;
-  if (tid == 0 && a.dbg) { unsigned long long T4 = wall_clock64(); gbuf[0] = T1 - T0; gbuf[1] = T2 - T1; gbuf[2] = T3 - T2; gbuf[3] = T4 - T3; gbuf[4] = K; }
+  if (tid == 0 && a.dbg) { unsigned long long T4 = wall_clock64(); gbuf[0] = T4 - T0; gbuf[1] = Tsel; gbuf[2] = Tsort; gbuf[3] = Tgreedy; gbuf[4] = K; }
 }
 
 static inline int next_pow2(int v) {
@@ -331,7 +422,7 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   if (n < 1 || nc < 1 || a < 1 || max_det < 1 || max_nms < 1 || (long)a * nc > 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: n=%d nc=%d a=%d max_det=%d", n, nc, a, max_det);
   multi_label = multi_label && nc > 1;   // ops.py:196
   if (ws_bytes < mgdt_nms_workspace_bytes(n, nc, a, multi_label, max_nms)) MGDT_FAIL(MGDT_WORKSPACE, "nms: workspace too small");
-  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)6 * max_det * sizeof(float);
+  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)(5 * max_det + (max_det & 1)) * sizeof(float) + (size_t)max_det * sizeof(u64);
   if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: max_det=%d too large for the LDS kept list", max_det);
   NmsArgs g;
   g.dbg = getenv("MGDT_NMS_DBG") != nullptr;

@@ -19,4 +19,4 @@ for _ in range(2):
 torch.cuda.synchronize()
 per = wsb // 8 // b
 for i in (0, 1, 31):
-    print('img', i, 'ticks(10ns) count/compact/sort/greedy, K:', ws[i * per:i * per + 5].tolist(), 'kept', int(cnt[i]))
+    print('img', i, 'ticks(10ns) total / select+compact / sort / greedy, K:', ws[i * per:i * per + 5].tolist(), 'kept', int(cnt[i]))
