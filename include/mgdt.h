@@ -76,6 +76,16 @@ size_t mgdt_cnx_mlp_workspace_bytes(int n, int h, int w, int c);
 int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packed, const float* gamma, const float* beta, void* ws,
                      const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- layers 0 and 1 of every YOLOv8 graph (Conv 3->16 k3 s2, Conv 16->32 k3 s2, both + BN + SiLU; models/v8/*.yaml rows 0-1) in one
+ * launch, bf16 path: the image patch is staged in LDS with 16-byte row loads, layer 0 runs on MFMA out of LDS, its map never leaves the
+ * CU.  x: N x 3 x H x W NCHW image (any strides), x_dtype MGDT_BF16 / MGDT_F32 / MGDT_U8 (u8 is divided by 255 like
+ * yolo/engine/predictor.py:129); y: N x H/4 x W/4 x 32 bf16 NHWC.  packed0 = mgdt_stem2_pack(W' of layer 0, fp32 [16][3][3][3] with the
+ * BatchNorm scale folded in as fuse_conv_and_bn does), bias0[16]; packed1 / bias1 = mgdt_conv_pack(16, 32, 3, MGDT_BF16). */
+size_t mgdt_stem2_packed_bytes(void);
+int mgdt_stem2_pack(const float* w_folded, void* packed, mgdt_stream s);
+int mgdt_stem2_fwd(const mgdt_view* x, int x_dtype, const void* packed0, const float* bias0, const void* packed1, const float* bias1,
+                   const mgdt_view* y, mgdt_stream s);
+
 /* ---- a whole CSP block (MSPA_C2f / C2f) in one launch, bf16 inference (nn/modules/block.py:187-287, :514-526):
  *   mode 0 (MSPA_C2f): front = the three chained 1x1 convs of mgdt_pw_chain3_fwd (blob of mgdt_pw_chain_pack), bottleneck input
  *                      sp2 + x[3wd:4wd]; concat = [sp0 | sp1 | sp2 | b_0 .. b_{n-1}]

@@ -80,12 +80,36 @@ class BaseModel(nn.Module):
             for m in self.modules():
                 m.__dict__.pop('_ctx', None)
         y = []
-        for m in self.model:
+        layers = self.model
+        if not self.training and self._stem_fusable(x):
+            # layers 0 and 1 (two stride-2 3x3 Convs) in one launch: layer 0's map never reaches HBM (mgdt_stem2_fwd)
+            m0, m1 = self.model[0], self.model[1]
+            pk0 = m0._cached(('stem2',), [m0.conv.weight, m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var],
+                             lambda: ops.PackedStem2(m0.conv.weight, (m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var, m0.bn.eps)))
+            x = ops.stem2(x, pk0, m1.packed(torch.bfloat16, direct=False))
+            y = [None, x if 1 in self.save else None]
+            layers = list(self.model)[2:]
+        for m in layers:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
             x = m(x)
             y.append(x if m.i in self.save else None)
         return x
+
+    def _stem_fusable(self, x):
+        """layers 0, 1 = Conv(3, 16, 3, 2) -> Conv(16, 32, 3, 2) with BN + SiLU, bf16 compute, layer 0's output used by layer 1 only, and nobody
+        watching the individual layers (forward hooks)"""
+        if not ops.FUSED_STEM or getattr(self, 'compute_dtype', None) != torch.bfloat16 or len(self.model) < 3 or 0 in self.save:
+            return False
+        if x.dtype not in (torch.bfloat16, torch.float32, torch.uint8) or x.dim() != 4 or x.shape[1] != 3:
+            return False
+        m0, m1 = self.model[0], self.model[1]
+        for m, (ci, co) in ((m0, (3, 16)), (m1, (16, 32))):
+            if not (isinstance(m, Conv) and not isinstance(m, DWConv) and hasattr(m, 'bn') and isinstance(m.act, nn.SiLU) and m.f == -1 and not m._forward_hooks
+                    and m.conv.kernel_size == (3, 3) and m.conv.stride == (2, 2) and m.conv.padding == (1, 1) and m.conv.groups == 1 and m.conv.bias is None
+                    and m.conv.in_channels == ci and m.conv.out_channels == co):
+                return False
+        return True
 
     def backward(self, head_grads, layer_done=None):
         """Explicit reverse pass over the layer list (the counterpart of `_predict_once`; replaces torch.autograd on the

@@ -216,6 +216,37 @@ def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=No
     return out
 
 
+# ------------------------------------------------------------------ layers 0 + 1 in one launch
+FUSED_STEM = True        # tests flip this to compare against the two conv launches
+
+
+class PackedStem2:
+    """Layer-0 weights (3 -> 16, k3 s2, BN folded exactly as fuse_conv_and_bn) in the fragment order of mgdt_stem2_fwd + bias."""
+
+    def __init__(self, weight, bn):
+        g, b, mu, var, eps = bn
+        scale = (g.detach().float() / torch.sqrt(eps + var.detach().float()))
+        wf = (weight.detach().float() * scale.view(-1, 1, 1, 1)).contiguous()
+        self.bias = (b.detach().float() - g.detach().float() * mu.detach().float() / torch.sqrt(var.detach().float() + eps)).contiguous()
+        self.blob = torch.empty(L.lib().mgdt_stem2_packed_bytes(), dtype=torch.uint8, device=weight.device)
+        L.check(L.lib().mgdt_stem2_pack(ptr(wf), ptr(self.blob), stream()), 'stem2_pack')
+
+
+def stem2(x, pk0, pk1):
+    """x (B, 3, H, W) NCHW image (bf16 / fp32 / uint8) -> SiLU(conv1(SiLU(conv0(x)))) as (B, 32, H/4, W/4) bf16 NHWC."""
+    _need_gpu(x)
+    b, _, h, w = x.shape
+    h0, w0 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    h1, w1 = (h0 - 1) // 2 + 1, (w0 - 1) // 2 + 1
+    y = new_act(b, 32, h1, w1, torch.bfloat16, x.device)
+    if _PROF is not None:
+        _META['stem2_fwd'] = dict(shape=(b, 3, h, w, 32, 3, 4), flops=2.0 * b * (h0 * w0 * 16 * 27 + h1 * w1 * 32 * 144),
+                                  bytes=float(x.numel() * x.element_size() + y.numel() * 2))
+    _launch('stem2_fwd', 'mgdt_stem2_fwd', vp(x), U8 if x.dtype == torch.uint8 else dtype_code(x.dtype), ptr(pk0.blob), ptr(pk0.bias), ptr(pk1.w), ptr(pk1.bias),
+            vp(y), stream())
+    return y
+
+
 # ------------------------------------------------------------------ whole CSP block (MSPA_C2f / C2f) in one launch
 FUSED_CSP_BLOCK = True   # tests flip this to compare against the per-conv launch chain
 CSP_MSPA, CSP_C2F = 0, 1

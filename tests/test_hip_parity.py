@@ -206,6 +206,44 @@ def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
     assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('in_dtype', ['bf16', 'f32', 'u8'])
+@pytest.mark.parametrize('hw', [(64, 96), (37, 45), (640, 640), (30, 18)])
+def test_fused_stem_matches_two_conv_launches(in_dtype, hw):
+    """bf16 path: layers 0 + 1 in one launch (mgdt_stem2_fwd: image patch in LDS, layer 0 on MFMA with bf16 weights, its map kept on the CU)
+    vs the stem kernel (fp32 weights, VALU) + the implicit-GEMM conv.  Differences: bf16 rounding of the image / layer-0 weights only.
+    Odd sizes exercise the zero padding of both layers and partial tiles; uint8 the fused / 255."""
+    from mgdt_yolo_amd import ops
+    m = build_model('mspa_c2f_gd_yolov8', torch.bfloat16)
+    B = 2
+    img = seeded_images(B, hw[0], hw[1], seed=4)
+    if in_dtype == 'u8':
+        x = (img * 255).round().clamp_(0, 255).to(torch.uint8).to(DEV)
+        xf = x.float().cpu() / 255
+    elif in_dtype == 'bf16':
+        x = img.to(DEV).to(torch.bfloat16)
+        xf = x.float().cpu()
+    else:
+        x = img.to(DEV)
+        xf = img
+    assert m._stem_fusable(x)
+    m0, m1 = m.model[0], m.model[1]
+    with torch.no_grad():
+        pk0 = ops.PackedStem2(m0.conv.weight, (m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var, m0.bn.eps))
+        y_fused = ops.stem2(x, pk0, m1.packed(torch.bfloat16, direct=False)).float()
+        y_two = m1(m0(x)).float()
+    # fp64 reference of the two layers (BN folded) on the values the kernels see
+    import torch.nn.functional as F
+    from oracle import layers as OL
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    ref = OL.conv(OL.conv(xf.double(), sd, 'model.0', s=2, fused=True), sd, 'model.1', s=2, fused=True)
+    scale = ref.abs().max().item()
+    e_f, e_t = (y_fused.cpu().double() - ref).abs().max().item() / scale, (y_two.cpu().double() - ref).abs().max().item() / scale
+    print(f'stem {in_dtype} {hw}: fused vs fp64 {e_f:.2e}, two launches vs fp64 {e_t:.2e}')
+    assert y_fused.shape == y_two.shape == ref.shape
+    assert e_f < 2e-2 and e_t < 2e-2
+    assert (y_fused - y_two).abs().max().item() < 2e-2 * scale
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_stem_takes_uint8_images_like_the_reference_preprocess(dtype):
     """uint8 NCHW image -> stem with /255 fused (predictor.py:129) == float image / 255 fed to the same stem, bit for bit."""
@@ -476,8 +514,10 @@ def test_e2e_bf16_stated_tolerance(golden, tag):
 
 # bf16 throughput path vs the fp32 REFERENCE: stated tolerances = ~2x the errors measured on MI355X (printed by the tests; round 2:
 # see DESIGN.md section 4).  (max box error in px, max confidence error) over every anchor / class of the compared outputs.
-BF16_TOL = {'mspa_c2f_gd_n': (1.5, 0.05), 'yolov8_n': (1.5, 0.05)}
-BF16_TOL_640 = {'mspa_c2f_gd_n': (1.5, 0.05), 'yolov8_n': (1.5, 0.05)}
+# measured (round 2, gpurun_out/r2_*): 2x160x160: mspa 0.68 px / 0.034, yolov8 0.23 px / 0.0031; 1x640x640: mspa 0.83 px / 0.048 (mean box error
+# 0.14 px), yolov8 0.53 px / 0.0064.  The MSPA-GD graph is deeper in bf16 ops (attention scaling, ConvNeXt blocks, injection) than stock yolov8.
+BF16_TOL = {'mspa_c2f_gd_n': (1.4, 0.07), 'yolov8_n': (0.5, 0.008)}
+BF16_TOL_640 = {'mspa_c2f_gd_n': (1.7, 0.10), 'yolov8_n': (1.1, 0.015)}
 
 
 @pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
@@ -904,11 +944,11 @@ def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
     x = seeded_images(8, 640, 640, seed=100).to(DEV).to(torch.bfloat16)
     with torch.no_grad():
         y_on = m(x)[0].float()
-        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = False
+        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = False
         try:
             y_off = m(x)[0].float()
         finally:
-            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = True
+            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = True
     assert not torch.equal(y_on, y_off)                      # the switches really changed the launch sequence
     m32 = build_model('mspa_c2f_gd_yolov8', torch.float32)
     with torch.no_grad():

@@ -22,7 +22,7 @@ ap.add_argument('--reps', type=int, default=5)
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
 m = seed_state_dict_(DetectionModel(get_config(a.model, a.scale, 80), verbose=False), 0).eval().cuda().set_compute_dtype(dt)
-x = seeded_images(a.batch, a.imgsz, a.imgsz, seed=100).cuda()
+x = seeded_images(a.batch, a.imgsz, a.imgsz, seed=100).cuda().to(dt)      # the image in the compute dtype, as bench.py feeds it
 with torch.no_grad():
     for _ in range(2):
         y, _ = m(x)
