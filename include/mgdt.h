@@ -161,12 +161,13 @@ int mgdt_conv2d_direct_fwd(const mgdt_view* x, int x_dtype, const float* w_gemm,
  * pool: x (n,h,w,c) -> pooled fp32 [n][MGDT_SPR_SPLITS][c][5]: per row-band partial SUMS of {whole map, the four
  *       adaptive_avg_pool2d(2) bins (row-major)} (fixed reduction order: results are run-to-run identical);
  * attn: finishes the means, runs fc1/ReLU/fc2/sigmoid on each of the `groups` channel groups (shared weights,
- *       fc1_w [cw/4][5cw], fc2_w [cw][cw/4], cw = c/groups), softmax over the groups -> attn fp32 [n][c];
+ *       fc1_w [cw/4][5cw], fc2_w [cw][cw/4], cw = c/groups), softmax over the groups (softmax = 1; 0 = the bare sigmoid weights of
+ *       SPRModule.forward, spr_module.py:20-31) -> attn fp32 [n][c];
  * scale: y = x * attn[n,c].                                                                               */
 #define MGDT_SPR_SPLITS 16
 int mgdt_spr_pool_fwd(const mgdt_view* x, float* pooled, int dtype, mgdt_stream s);
 int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w,
-                      const float* fc2_b, int n, int c, int groups, int h, int w, float* attn, mgdt_stream s);
+                      const float* fc2_b, int n, int c, int groups, int h, int w, int softmax, float* attn, mgdt_stream s);
 int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, const mgdt_view* y, int dtype, mgdt_stream s);
 /* spr_attn + scale_channels in one launch: every workgroup recomputes its image's attention (same order, same bits) and scales
  * a share of the pixels: y = x * softmax_groups(SPR(pooled)).  `pooled` as written by mgdt_spr_pool_fwd (nsplit = MGDT_SPR_SPLITS, or 0)
@@ -290,6 +291,25 @@ int mgdt_grad_clip_coef(const float* g, long n, float max_norm, float* out2, voi
 int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float lr_bias, float momentum, int nesterov,
                   int first, const float* clip2, mgdt_stream s);
 int mgdt_ema_update(float* ema, const float* p, long n, float decay, mgdt_stream s);
+
+/* ---- box helpers, validator reductions, predictor preprocess; fp32 boxes, rows of `row` >= 4 floats ------------
+ * box_convert: mode 0 = xywh2xyxy (yolo/utils/ops.py:362-377), 1 = xyxy2xywh (:345-359); columns >= 4 are copied.
+ * box_iou: pairwise IoU (n,4) x (m,4) -> (n,m), eps in the union (yolo/utils/metrics.py:52-72).
+ * bbox_iou: row i of box1 (stride1 floats; 0 broadcasts one box) vs row i of box2; mode 0 IoU, 1 GIoU, 2 DIoU, 3 CIoU (metrics.py:75-128).
+ * scale_boxes: in place (b - pad) / gain, then clip to [0, w0] x [0, h0] (ops.py:90-117 + clip_boxes :269-285).
+ * letterbox: one uint8 HWC BGR image -> uint8 CHW RGB planes of the letter-boxed batch tensor (augment.py:538-593 geometry computed by the
+ *   caller; resize = cv2 INTER_LINEAR 8-bit rule, border 114; predictor.py:123-125 BGR->RGB, HWC->CHW).
+ * ap_per_class: the per-class part of metrics.py:410-497 (cumulative TP/FP, recall / precision, compute_ap's envelope + 101-point
+ *   interpolation in numpy's own arithmetic order, the 1000-point P/R-vs-confidence curves); inputs grouped by class, descending confidence. */
+int mgdt_box_convert(const float* in, float* out, long n, int row, int mode, mgdt_stream s);
+int mgdt_box_iou(const float* b1, int n, const float* b2, int m, float eps, float* out, mgdt_stream s);
+int mgdt_bbox_iou(const float* b1, int stride1, const float* b2, int stride2, long n, int xywh, int mode, float eps, float* out, mgdt_stream s);
+int mgdt_scale_boxes(float* boxes, long n, int row, float gain, float padx, float pady, float h0, float w0, mgdt_stream s);
+int mgdt_letterbox_fwd(const void* src_hwc_bgr, int sh, int sw, long src_pitch, void* dst_chw_rgb, int dh, int dw, int new_h, int new_w, int top,
+                       int left, mgdt_stream s);
+size_t mgdt_ap_workspace_bytes(int n_det, int n_cls);
+int mgdt_ap_per_class(const void* tp, const float* conf, const int32_t* seg, const int32_t* nlab, int n_det, int n_cls, int T, const double* x101,
+                      const double* px, double eps, void* ws, double* ap, double* pcur, double* rcur, mgdt_stream s);
 
 #ifdef __cplusplus
 }

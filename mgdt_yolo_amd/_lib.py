@@ -33,7 +33,7 @@ PROTOTYPES = {
     'mgdt_conv_pack_direct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_direct_fwd': (_i, [VP, _i, _vp, _vp, _i, _i, _i, _i, VP, _i, _vp]),
     'mgdt_spr_pool_fwd': (_i, [VP, _vp, _i, _vp]),
-    'mgdt_spr_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'mgdt_spr_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mgdt_scale_channels_fwd': (_i, [VP, _vp, VP, _i, _vp]),
     'mgdt_sppf_pool_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),
     'mgdt_adaptive_avgpool_fwd': (_i, [VP, VP, _i, _vp]),
@@ -96,6 +96,13 @@ PROTOTYPES = {
     'mgdt_grad_clip_coef': (_i, [_vp, C.c_long, _f, _vp, _vp, _vp]),
     'mgdt_sgd_step': (_i, [_vp, _vp, _vp, _vp, C.c_long, _f, _f, _f, _i, _i, _vp, _vp]),
     'mgdt_ema_update': (_i, [_vp, _vp, C.c_long, _f, _vp]),
+    'mgdt_box_convert': (_i, [_vp, _vp, C.c_long, _i, _i, _vp]),
+    'mgdt_box_iou': (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
+    'mgdt_bbox_iou': (_i, [_vp, _i, _vp, _i, C.c_long, _i, _i, _f, _vp, _vp]),
+    'mgdt_scale_boxes': (_i, [_vp, C.c_long, _i, _f, _f, _f, _f, _f, _vp]),
+    'mgdt_letterbox_fwd': (_i, [_vp, _i, _i, C.c_long, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mgdt_ap_workspace_bytes': (_sz, [_i, _i]),
+    'mgdt_ap_per_class': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

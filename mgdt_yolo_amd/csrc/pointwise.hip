@@ -201,7 +201,7 @@ extern "C" int mgdt_spr_pool_fwd(const mgdt_view* x, float* pooled, int dtype, m
 __global__ __launch_bounds__(256) void spr_attn_kernel(const float* __restrict__ partial, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, int C, int G, int H, int W,
-                                                       float* __restrict__ attn) {
+                                                       int do_softmax, float* __restrict__ attn) {
   extern __shared__ float sm[];
   const int n = blockIdx.x, cw = C / G, hid = cw / 4;
   float* pooled = sm;               // [C][5] means
@@ -233,6 +233,10 @@ __global__ __launch_bounds__(256) void spr_attn_kernel(const float* __restrict__
     obuf[o] = 1.f / (1.f + expf(-acc));
   }
   __syncthreads();
+  if (!do_softmax) {                               // the module's standalone form: sigmoid weights (spr_module.py:27-31)
+    for (int o = threadIdx.x; o < C; o += 256) attn[(long)n * C + o] = obuf[o];
+    return;
+  }
   for (int c = threadIdx.x; c < cw; c += 256) {   // softmax over the G groups (block.py:278)
     float mx = -INFINITY;
     for (int gi = 0; gi < G; ++gi) mx = fmaxf(mx, obuf[gi * cw + c]);
@@ -243,12 +247,12 @@ __global__ __launch_bounds__(256) void spr_attn_kernel(const float* __restrict__
 }
 
 extern "C" int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const float* fc1_b, const float* fc2_w,
-                                 const float* fc2_b, int n, int c, int groups, int h, int w, float* attn, mgdt_stream s) {
+                                 const float* fc2_b, int n, int c, int groups, int h, int w, int softmax, float* attn, mgdt_stream s) {
   if (!pooled || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !attn) MGDT_FAIL(MGDT_BAD_ARG, "spr_attn: null pointer");
   if (groups < 1 || c % groups || (c / groups) % 4 || c > 4096 || h < 1 || w < 1) MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn: c=%d groups=%d", c, groups);
   int cw = c / groups, hid = cw / 4;
   size_t lds = (size_t)(c * 5 + groups * hid + c) * sizeof(float);
-  spr_attn_kernel<<<n, 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, h, w, attn);
+  spr_attn_kernel<<<n, 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, h, w, softmax, attn);
   MGDT_CHECK_LAUNCH("spr_attn_fwd");
   return MGDT_OK;
 }

