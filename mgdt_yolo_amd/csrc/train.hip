@@ -4,6 +4,8 @@
 // routing), channel-vectorised; the MFMA treatment the forward convolution got is the next step for dgrad(stride 2) / wgrad.
 // Reference semantics: nn.BatchNorm2d(eps 1e-3, momentum 0.03) as set by initialize_weights (yolo/utils/torch_utils.py:254-256):
 // normalise with the biased batch variance, update running_var with the unbiased one.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define RED_SPLITS 512
@@ -269,6 +271,9 @@ extern "C" int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, 
   return MGDT_OK;
 }
 
+bool mgdt_wgrad_mfma_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* partial, int nsplit, int dtype,
+                            hipStream_t st);   // wgrad_mfma.hip
+
 // ------------------------------------------------------------------------------------------------ conv wgrad (+ bias grad)
 // dw[co][ci][ky][kx] = sum_{n,oy,ox} dy[n,oy,ox,co] * (x [+ x2])[n, oy*s-pad+ky, ox*s-pad+kx, ci]
 // block = one tap x 16 couts x 16 cins x one pixel split; 256 threads = 16 (co quad, ci quad) pairs x 16 pixel lanes.
@@ -414,8 +419,11 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
   mgdt_view b = (x2 && x2->p) ? *x2 : null_view();
   const int nsplit = wgrad_splits(x->c, dy->c, k);
   if ((long)dy->n * dy->h * dy->w >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: too many pixels");
-  dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * nsplit);
-  MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
+  static const bool no_mfma = getenv("MGDT_WGRAD_VALU") != nullptr;     // experiment knob: the VALU outer-product kernel
+  if (no_mfma || !mgdt_wgrad_mfma_launch(x, x2, dy, k, stride, (float*)ws, nsplit, dtype, st)) {
+    dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * nsplit);
+    MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
+  }
   long n = (long)dy->c * x->c * k * k;
   wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
   if (dbias) {

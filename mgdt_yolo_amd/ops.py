@@ -645,6 +645,10 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         copy(dw4[:, :c], dw)
         return
     ws = torch.empty(lib.mgdt_conv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k), dtype=torch.uint8, device=x.device)
+    if _PROF is not None:
+        b, ci, h, w = x.shape
+        _META['conv_wgrad'] = dict(shape=(b, ci, h, w, dy.shape[1], k, stride), flops=2.0 * dy.numel() * ci * k * k,
+                                   bytes=float(x.numel() * x.element_size() + dy.numel() * dy.element_size()))
     _launch('conv_wgrad', 'mgdt_conv_wgrad', vp(x), vp(x2), vp(dy), k, stride, ptr(dw), ptr(dbias), int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
 
 
