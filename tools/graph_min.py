@@ -51,7 +51,10 @@ def case_conv_avgpool():
     return ops.adaptive_avgpool(t, ops.new_act(32, 128, 10, 10, torch.bfloat16, dev))
 mk128 = mk(128, 20, 20)
 with torch.no_grad():
-    for name, fn in [('conv -> bilinear', case_conv_bilinear)]:
+    def case_conv_only():
+        return conv(xin)
+    for name, fn in [('conv -> bilinear', case_conv_bilinear), ('bilinear only', case_bilinear_only), ('conv only', case_conv_only), ('conv -> copy', case_conv_copy),
+                     ('aten -> bilinear', case_aten_bilinear), ('conv -> aten', case_conv_aten), ('conv -> avgpool', case_conv_avgpool), ('conv chain', case_conv_chain)]:
         ref = fn().clone(); torch.cuda.synchronize()
         side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
