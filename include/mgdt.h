@@ -86,6 +86,14 @@ int mgdt_stem2_pack(const float* w_folded, void* packed, mgdt_stream s);
 int mgdt_stem2_fwd(const mgdt_view* x, int x_dtype, const void* packed0, const float* bias0, const void* packed1, const float* bias1,
                    const mgdt_view* y, mgdt_stream s);
 
+/* ---- Detect head tail in one launch, bf16 (nn/modules/head.py:150-177): the two final 1x1 convs with bias (box c2 -> 16, cls c3 -> nc), the raw
+ * (N, 16+nc, H, W) map and its decode (DFL expectation, dist2bbox, stride, sigmoid) into y[N][4+nc][a_total] at anchor offset a_off.
+ * wb/bb, wc/bc: mgdt_conv_pack(c2, 16, 1, bf16) / mgdt_conv_pack(c3, nc, 1, bf16) with the conv biases.  reg_max must be 4 (this fork's
+ * Detect); other heads keep mgdt_conv2d_fwd + mgdt_detect_decode_fwd. */
+int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, int dtype);
+int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
+                         float stride, int a_off, int a_total, const mgdt_view* feat, float* y, mgdt_stream s);
+
 /* ---- a whole CSP block (MSPA_C2f / C2f) in one launch, bf16 inference (nn/modules/block.py:187-287, :514-526):
  *   mode 0 (MSPA_C2f): front = the three chained 1x1 convs of mgdt_pw_chain3_fwd (blob of mgdt_pw_chain_pack), bottleneck input
  *                      sp2 + x[3wd:4wd]; concat = [sp0 | sp1 | sp2 | b_0 .. b_{n-1}]

@@ -1,0 +1,166 @@
+// Detect head tail in one launch (bf16 inference): the two final 1x1 convolutions with bias (box: c2 -> 4*reg_max, cls: c3 -> nc), the
+// raw (B, no, H, W) map the head returns, and the decode - DFL softmax-expectation, dist2bbox, stride, sigmoid - into y (B, 4+nc, A).
+// Reference: nn/modules/head.py:150-177 (cv2[i][2], cv3[i][2], torch.cat, DFL, dist2bbox), nn/modules/block.py:36-54, yolo/utils/tal.py:491-500.
+// Unfused this was three launches (11 + 26 + 45 us at B=32, 80x80) that wrote the 39 MB map and read it back for the decode.
+//
+// A wave takes 32 consecutive anchors of one image (two 16-pixel MFMA groups).  Activations go global -> VGPR in fragment order (a lane
+// loads the 16 bytes it feeds to the MFMA); both weight panels (mgdt_conv_pack layout) sit in LDS for the whole persistent workgroup.
+// reg_max = 4 makes the box epilogue lane-local: lane (r, g) of the 16-output box tile holds exactly the four DFL bins of side g of
+// anchor r, so the softmax-expectation needs no cross-lane traffic; the four sides meet through three shuffles for dist2bbox.  Decoded
+// values are staged per wave as a [4+nc][32] fp32 tile in LDS and leave as 128-byte runs along the anchor axis of y.
+// The decode consumes the bf16-ROUNDED logits (what the separate decode kernel read back from the map), so both paths agree.
+#include "conv_igemm_kernel.h"
+
+struct DtArgs {
+  const char* tb; int bsn, bsh, bsw; uint32_t tb_bytes;
+  const char* tc; int csn, csh, csw; uint32_t tc_bytes;
+  char* feat; int fsn, fsh, fsw; uint32_t feat_bytes;
+  const char* wb; const float* bb; const char* wc; const float* bc;
+  float* y;
+  int N, H, W, HW, c2, c3, nc, kch, nbc, units_per_img, units, a_off, a_total;
+  float stride;
+  FastDiv fd_w;
+};
+
+constexpr int DT_THREADS = 256;
+constexpr int DT_LD = 33;               // row pitch (floats) of a wave's [4+nc][32] output tile
+
+__global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbl = smem;                                       // box panel: 1 chunk x 1 block
+  char* wcl = smem + 1024;                                // cls panel: kch x nbc blocks of 1 KiB
+  float* biasl = (float*)(wcl + (size_t)a.kch * a.nbc * 1024);       // [16] box | [nbc*16] cls
+  float* ytile = biasl + 16 + a.nbc * 16;                 // [4 waves][4+nc][DT_LD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < 64; i += DT_THREADS) ((uint4*)wbl)[i] = ((const uint4*)a.wb)[i];
+  for (int i = tid; i < a.kch * a.nbc * 64; i += DT_THREADS) ((uint4*)wcl)[i] = ((const uint4*)a.wc)[i];
+  for (int i = tid; i < 16 + a.nbc * 16; i += DT_THREADS) biasl[i] = i < 16 ? a.bb[i] : a.bc[i - 16];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tb, 0, a.tb_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tc, 0, a.tc_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, a.feat_bytes, 0x00020000);
+  float* yt = ytile + (size_t)wave * (4 + a.nc) * DT_LD;
+  const char* wlane_b = wbl + lane * 16;
+  const char* wlane_c = wcl + lane * 16;
+  const int boff = (8 * g < a.c2) ? g * 16 : MGDT_OOB;    // box input: one K chunk, pieces past c2 are zero
+  const int r4 = 16;                                      // 4 * reg_max
+
+  for (int unit = blockIdx.x * 4 + wave; unit < a.units; unit += gridDim.x * 4) {
+    const int n = unit / a.units_per_img, a0 = (unit - n * a.units_per_img) * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int an = a0 + u * 16 + r;
+      const bool pv = an < a.HW;
+      const int oy = (int)fdiv((uint32_t)(pv ? an : 0), a.fd_w), ox = (pv ? an : 0) - oy * a.W;
+      const int bo = pv ? n * a.bsn + oy * a.bsh + ox * a.bsw : MGDT_OOB;
+      const int co = pv ? n * a.csn + oy * a.csh + ox * a.csw : MGDT_OOB;
+      const int fo = pv ? n * a.fsn + oy * a.fsh + ox * a.fsw : MGDT_OOB;
+      // ---- box branch: 16 outputs = 4 sides x 4 bins; lane (r, g): bins of side g
+      const bf16x8 Bb = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, (bo | boff) < 0 ? (uint32_t)MGDT_OOB : (uint32_t)(bo + boff), 0, 0));
+      bf16x8 Bc[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const int piece = kc * 4 + g;
+        const bool ok = kc < a.kch && piece * 8 < a.c3;
+        Bc[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(crs, (ok && co >= 0) ? (uint32_t)(co + piece * 16) : (uint32_t)MGDT_OOB, 0, 0));
+      }
+      f32x4 accb = *(const f32x4*)(biasl + 4 * g);
+      accb = mma(*(const bf16x8*)wlane_b, Bb, accb);
+      float lb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lb[j] = (float)(bf16)accb[j];                // the stored (rounded) logits are what gets decoded
+      bstore4<bf16>(frs, (uint32_t)fo + (uint32_t)(4 * g * 2), f32x4{lb[0], lb[1], lb[2], lb[3]});
+      // DFL (block.py:36-54): softmax over the 4 bins, expectation with weights 0..3
+      const float mx = fmaxf(fmaxf(lb[0], lb[1]), fmaxf(lb[2], lb[3]));
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = expf(lb[k] - mx);
+        den += e;
+        num += e * (float)k;
+      }
+      const float dd = num / den;
+      const float dl = __shfl(dd, r, 64), dt = __shfl(dd, 16 + r, 64), dr = __shfl(dd, 32 + r, 64), db = __shfl(dd, 48 + r, 64);
+      const float ax = (float)ox + 0.5f, ay = (float)oy + 0.5f;            // make_anchors offset 0.5 (tal.py:476-488)
+      const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;       // dist2bbox (tal.py:491-500), then * stride (head.py:176)
+      const float comp = g == 0 ? (x1 + x2) / 2.f * a.stride : g == 1 ? (y1 + y2) / 2.f * a.stride : g == 2 ? (x2 - x1) * a.stride : (y2 - y1) * a.stride;
+      yt[g * DT_LD + u * 16 + r] = comp;
+      // ---- class branch
+      for (int nb = 0; nb < a.nbc; ++nb) {
+        f32x4 acc = *(const f32x4*)(biasl + 16 + nb * 16 + 4 * g);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+          if (kc < a.kch) acc = mma(*(const bf16x8*)(wlane_c + (size_t)(kc * a.nbc + nb) * 1024), Bc[kc], acc);
+        const int c = nb * 16 + 4 * g;
+        float lc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lc[j] = (float)(bf16)acc[j];
+        bstore4<bf16>(frs, c < a.nc ? (uint32_t)fo + (uint32_t)((r4 + c) * 2) : (uint32_t)MGDT_OOB, f32x4{lc[0], lc[1], lc[2], lc[3]});
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < a.nc) yt[(4 + c + j) * DT_LD + u * 16 + r] = 1.f / (1.f + expf(-lc[j]));
+      }
+    }
+    // the wave's [4+nc][32] tile -> y rows (128-byte runs along the anchor axis); a wave's LDS accesses complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* yo = a.y + (size_t)n * (4 + a.nc) * a.a_total + a.a_off + a0;
+    const int col = lane & 31, rsel = lane >> 5;
+    for (int row = rsel; row < 4 + a.nc; row += 2)
+      if (a0 + col < a.HW) yo[(size_t)row * a.a_total + col] = yt[row * DT_LD + col];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+/* tb: N x H x W x c2 box-branch input, tc: N x H x W x c3 class-branch input (bf16 NHWC views); wb/bb = mgdt_conv_pack(c2, 16, 1, bf16) of
+ * cv2[i][2] (4*reg_max = 16 outputs: reg_max must be 4), wc/bc = mgdt_conv_pack(c3, nc, 1, bf16) of cv3[i][2]; feat: N x H x W x (16+nc) raw
+ * head map (written); y: fp32 [N][4+nc][a_total], this level's anchors at a_off.  Covered: c2 <= 32, c3 <= 128, nc <= 256; returns 1 from
+ * mgdt_detect_tail_supported when so. */
+extern "C" int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, int dtype) {
+  return dtype == MGDT_BF16 && reg_max == 4 && c2 % 8 == 0 && c2 <= 32 && c3 % 8 == 0 && c3 <= 128 && nc >= 4 && nc <= 256 && nc % 4 == 0;   // nc % 4: 8-byte rows of the raw map
+}
+
+extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
+                                    float stride, int a_off, int a_total, const mgdt_view* feat, float* y, mgdt_stream s) {
+  if (!view_ok(tb) || !view_ok(tc) || !view_ok(feat) || !wb || !bb || !wc || !bc || !y) MGDT_FAIL(MGDT_BAD_ARG, "detect_tail: null/empty argument");
+  if (!mgdt_detect_tail_supported(tb->c, tc->c, nc, 4, MGDT_BF16)) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: c2=%d c3=%d nc=%d not covered", tb->c, tc->c, nc);
+  if (feat->c != 16 + nc || tb->n != tc->n || tb->h != tc->h || tb->w != tc->w || feat->n != tb->n || feat->h != tb->h || feat->w != tb->w ||
+      a_off < 0 || a_off + tb->h * tb->w > a_total)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: shapes");
+  DtArgs a;
+  memset(&a, 0, sizeof(a));
+  bool fits = true;
+  auto bind = [&](const mgdt_view* v, const char** p, int* sn, int* sh, int* sw, uint32_t* bytes, int q) {
+    const long ext = ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * 2;
+    if (v->sc != 1 || v->sw % q || v->sh % q || v->sn % q || (uintptr_t)v->p % (q * 2) || ext >= 0x7fffffffL) { fits = false; return; }
+    *p = (const char*)v->p; *sn = (int)(v->sn * 2); *sh = (int)(v->sh * 2); *sw = (int)(v->sw * 2); *bytes = (uint32_t)ext;
+  };
+  const char* fp = nullptr;
+  bind(tb, &a.tb, &a.bsn, &a.bsh, &a.bsw, &a.tb_bytes, 8);
+  bind(tc, &a.tc, &a.csn, &a.csh, &a.csw, &a.tc_bytes, 8);
+  bind(feat, &fp, &a.fsn, &a.fsh, &a.fsw, &a.feat_bytes, 4);
+  if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: views must be 16-byte aligned NHWC (sc == 1) below 2 GiB");
+  a.feat = (char*)fp;
+  a.wb = (const char*)wb; a.bb = bb; a.wc = (const char*)wc; a.bc = bc; a.y = y;
+  a.N = tb->n; a.H = tb->h; a.W = tb->w; a.HW = tb->h * tb->w; a.c2 = tb->c; a.c3 = tc->c; a.nc = nc;
+  a.kch = cdiv(tc->c, 32); a.nbc = cdiv(nc, 16);
+  a.units_per_img = cdiv(a.HW, 32); a.units = a.N * a.units_per_img;
+  a.a_off = a_off; a.a_total = a_total; a.stride = stride; a.fd_w = make_fastdiv((uint32_t)tb->w);
+  const size_t lds = 1024 + (size_t)a.kch * a.nbc * 1024 + (size_t)(16 + a.nbc * 16) * 4 + (size_t)4 * (4 + nc) * DT_LD * 4;
+  if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: nc=%d needs %zu B of LDS", nc, lds);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)detect_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "detect_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = 150 * 1024;
+  }
+  const int grid = std::min(cdiv(a.units, 4), 1024);
+  detect_tail_kernel<<<grid, DT_THREADS, lds, (hipStream_t)s>>>(a);
+  MGDT_CHECK_LAUNCH("detect_tail_fwd");
+  return MGDT_OK;
+}

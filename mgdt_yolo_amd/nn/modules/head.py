@@ -22,8 +22,14 @@ class _HeadConv(HipModule):
 
     @staticmethod
     def run(owner, conv, x, out):
-        pk = owner._cached((id(conv), out.dtype), [conv.weight, conv.bias],
-                           lambda: ops.PackedConv(conv.weight, conv.bias, None, 1, out.dtype))
+        # class counts that are not a multiple of 4 (the fork's own data: nc = 1 or 2) give raw maps whose pixel rows are not 8-byte aligned:
+        # those go through the direct kernel (element-wise stores), everything else through the MFMA kernel
+        q = 4
+        mfma = (conv.out_channels % q == 0 and out.stride(3) % q == 0 and out.stride(2) % q == 0 and out.stride(0) % q == 0 and
+                out.data_ptr() % (q * out.element_size()) == 0 and
+                ops.conv_can_mfma(x, conv.in_channels, conv.out_channels, 1, 1, 1, out.dtype))
+        pk = owner._cached((id(conv), out.dtype, mfma), [conv.weight, conv.bias],
+                           lambda: ops.PackedConv(conv.weight, conv.bias, None, 1, out.dtype, direct=not mfma))
         return ops.conv2d(x, pk, 1, ops.ACT_NONE, out=out)
 
     @staticmethod
@@ -61,6 +67,12 @@ class Detect(HipModule):
         like the reference (head.py:160)."""
         shape = x[0].shape
         r4 = 4 * self.reg_max
+        y, a_off, strides = None, 0, None
+        if not self.training:
+            strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])  # host copy, no sync per call
+            a_total = sum(t.shape[2] * t.shape[3] for t in x)
+            y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
+        decoded = [False] * self.nl
         for i in range(self.nl):
             xi = x[i]
             b, _, h, w = xi.shape
@@ -73,23 +85,32 @@ class Detect(HipModule):
             else:
                 tb = self.cv2[i][1](self.cv2[i][0](xi))      # Conv.forward: eval -> fused run, train -> batch-stat BN + ctx
                 tc = self.cv3[i][1](self.cv3[i][0](xi))
-            _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
-            _HeadConv.run(self, self.cv3[i][2], tc, feat[:, r4:])
+            if not self.training and ops.detect_tail_supported(tb, tc, self.nc, self.reg_max, feat.dtype):
+                # both final 1x1 convs, the raw map and the decode in one launch (mgdt_detect_tail_fwd)
+                pkb = self._cached((id(self.cv2[i][2]), feat.dtype), [self.cv2[i][2].weight, self.cv2[i][2].bias],
+                                   lambda c=self.cv2[i][2]: ops.PackedConv(c.weight, c.bias, None, 1, feat.dtype))
+                pkc = self._cached((id(self.cv3[i][2]), feat.dtype), [self.cv3[i][2].weight, self.cv3[i][2].bias],
+                                   lambda c=self.cv3[i][2]: ops.PackedConv(c.weight, c.bias, None, 1, feat.dtype))
+                ops.detect_tail(tb, tc, pkb, pkc, self.nc, strides[i], a_off, feat, y)
+                decoded[i] = True
+            else:
+                _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
+                _HeadConv.run(self, self.cv3[i][2], tc, feat[:, r4:])
             if self.training:
                 self._save_ctx((tb, tc))
+            else:
+                a_off += h * w
             x[i] = feat
         if self.training:
             return x
-        strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])  # host copy, no sync per call
         if self.dynamic or self.shape != shape:
             from ...yolo.utils.tal import make_anchors
             self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, strides, 0.5))
             self.shape = shape
-        a_total = sum(f.shape[2] * f.shape[3] for f in x)
-        y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
         a_off = 0
         for i, f in enumerate(x):
-            ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
+            if not decoded[i]:
+                ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
 

@@ -466,6 +466,24 @@ def detect_decode(feat, reg_max, nc, stride, a_off, y):
                                            stream())
 
 
+FUSED_DETECT_TAIL = True   # tests flip this to compare against conv + conv + decode
+
+
+def detect_tail_supported(tb, tc, nc, reg_max, dtype):
+    return bool(FUSED_DETECT_TAIL and dtype == torch.bfloat16 and tb.dtype == dtype and tc.dtype == dtype and is_nhwc(tb) and is_nhwc(tc) and
+                L.lib().mgdt_detect_tail_supported(tb.shape[1], tc.shape[1], int(nc), int(reg_max), dtype_code(dtype)))
+
+
+def detect_tail(tb, tc, pkb, pkc, nc, stride, a_off, feat, y):
+    """mgdt_detect_tail_fwd: final 1x1 convs of both branches + raw map `feat` + decode into y."""
+    if _PROF is not None:
+        b, _, h, w = tb.shape
+        _META['detect_tail_fwd'] = dict(shape=(b, tb.shape[1] + tc.shape[1], h, w, 16 + nc, 1, 1), flops=2.0 * b * h * w * (tb.shape[1] * 16 + tc.shape[1] * nc),
+                                        bytes=float((tb.numel() + tc.numel() + feat.numel()) * 2 + b * (4 + nc) * h * w * 4))
+    _launch('detect_tail_fwd', 'mgdt_detect_tail_fwd', vp(tb), vp(tc), ptr(pkb.w), ptr(pkb.bias), ptr(pkc.w), ptr(pkc.bias), int(nc), float(stride), int(a_off),
+            y.shape[2], vp(feat), ptr(y), stream())
+
+
 # ------------------------------------------------------------------ NMS
 def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, max_nms, max_wh):
     """pred (B, 4+nc, A) fp32 cuda contiguous -> (out [B,max_det,6], kept_anchor [B,max_det] int32, counts [B] int32)."""

@@ -206,6 +206,38 @@ def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
     assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('nc,ch,hws', [(80, (64,), [(80, 80)]), (4, (64,), [(13, 11)]), (3, (64,), [(9, 5)]), (80, (64, 128, 256), [(20, 24), (10, 12), (5, 6)]), (20, (32,), [(7, 9)])])
+def test_detect_tail_single_launch_matches_conv_conv_decode(nc, ch, hws):
+    """bf16: mgdt_detect_tail_fwd (both final 1x1 convs + raw map + DFL / dist2bbox / sigmoid decode) vs mgdt_conv2d_fwd x2 + mgdt_detect_decode_fwd.
+    Same packed weights and MFMA K order, the decode consumes the same bf16-rounded logits: the raw maps agree to a bf16 ulp, y to float rounding."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import Detect
+    m = seed_state_dict_(Detect(nc, ch), 4).eval()
+    m.stride = torch.tensor([8.0, 16.0, 32.0][:len(ch)])
+    m = m.to(DEV)
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.BatchNorm2d):
+            sub.eps = 1e-3
+        if hasattr(sub, 'out_dtype'):
+            sub._cdtype = torch.bfloat16
+    mk = lambda c, hw, s: torch.randn(2, c, *hw, generator=torch.Generator().manual_seed(s)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xs = [mk(c, hw, 7 + i) for i, (c, hw) in enumerate(zip(ch, hws))]
+    with torch.no_grad():
+        y_f, feats_f = m([t.clone() for t in xs])
+        ops.FUSED_DETECT_TAIL = False
+        try:
+            y_u, feats_u = m([t.clone() for t in xs])
+        finally:
+            ops.FUSED_DETECT_TAIL = True
+    for a, b in zip(feats_f, feats_u):
+        d = (a.float() - b.float()).abs().max().item()
+        assert d <= 2e-2 * b.float().abs().max().item(), d
+    eb, ec = (y_f[:, :4] - y_u[:, :4]).abs().max().item(), (y_f[:, 4:] - y_u[:, 4:]).abs().max().item()
+    print(f'detect tail nc={nc} ch={ch}: y box diff {eb:.4f} px, conf diff {ec:.5f}')
+    assert eb < 0.5 and ec < 2e-2
+    assert torch.isfinite(y_f).all() and y_f.shape == y_u.shape
+
+
 @pytest.mark.parametrize('in_dtype', ['bf16', 'f32', 'u8'])
 @pytest.mark.parametrize('hw', [(64, 96), (37, 45), (640, 640), (30, 18)])
 def test_fused_stem_matches_two_conv_launches(in_dtype, hw):
@@ -944,11 +976,11 @@ def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
     x = seeded_images(8, 640, 640, seed=100).to(DEV).to(torch.bfloat16)
     with torch.no_grad():
         y_on = m(x)[0].float()
-        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = False
+        ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = ops.FUSED_DETECT_TAIL = False
         try:
             y_off = m(x)[0].float()
         finally:
-            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = True
+            ops.FUSED_CNX_MLP = ops.FUSED_PW_CHAIN = ops.FUSED_INJECT = ops.FUSED_CSP_BLOCK = ops.FUSED_STEM = ops.FUSED_DETECT_TAIL = True
     assert not torch.equal(y_on, y_off)                      # the switches really changed the launch sequence
     m32 = build_model('mspa_c2f_gd_yolov8', torch.float32)
     with torch.no_grad():
