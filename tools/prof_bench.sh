@@ -2,6 +2,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/pb_$1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$1 -o t -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/$1_bench.json 2> $R/gpurun_out/$1_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_$1 -o t -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline > $R/gpurun_out/$1_bench.json 2> $R/gpurun_out/$1_bench.err
 cp $(find /tmp/pb_$1 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$1_kernel_stats.csv
 tail -1 $R/gpurun_out/$1_bench.json
