@@ -224,12 +224,10 @@ def main():
 
     if args.mode == 'train':
         from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
-        if args.dtype != 'f32':
-            raise SystemExit('bench.py --mode train: the training kernels compute in float32 (use --dtype f32)')
         nc = 80
         cfg = get_config(args.model, args.scale, nc)
         model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).to(dev)
-        tr = DetectionTrainer(model, world_size=world)
+        tr = DetectionTrainer(model, world_size=world, amp=args.dtype == 'bf16')      # bf16: activations / activation gradients in bf16, fp32 masters
         R = max(1, min(args.resident, 4))
         batches = []
         for r in range(R):

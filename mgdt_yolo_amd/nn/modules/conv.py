@@ -114,8 +114,6 @@ class Conv(HipModule):
         """act(bn_batchstats(conv(x [+ x2]))) [+ r1] [+ r2]; keeps (x, x2, raw conv output, mean, rstd) for backward()."""
         k, s = self._geometry()
         dt = self.out_dtype(x) if out is None else out.dtype
-        if dt != torch.float32:
-            raise NotImplementedError('training runs in float32 in this round (bf16 training kernels: next)')
         if self.conv.groups != 1:
             raise NotImplementedError('grouped / depth-wise Conv has no training kernels (weight and data gradients assume groups == 1); '
                                       'DWConv is not instantiated by any target YAML')

@@ -80,8 +80,6 @@ class ConvNeXtV2_Block(HipModule):
         gb = self._cached('grn', [self.grn.gamma, self.grn.beta],
                           lambda: (self.grn.gamma.detach().float().reshape(-1).contiguous(), self.grn.beta.detach().float().reshape(-1).contiguous()))
         if self.training:
-            if dt != torch.float32:
-                raise NotImplementedError('training runs in float32 in this round')
             pw1_raw = self._cached(('pw1raw', dt), [self.pwconv1.weight],
                                    lambda: ops.PackedConv(self.pwconv1.weight.detach().reshape(4 * dim, dim, 1, 1), None, None, 1, dt))
             return self._train_fwd(x, dw, pw1_raw, pw2, gb)

@@ -103,6 +103,15 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _same(*ts):
+    """Views that one kernel addresses with ONE dtype code must really share it: a bf16 map read as fp32 is an out-of-bounds access on the device,
+    so the mismatch is refused here."""
+    ts = [t for t in ts if t is not None]
+    for t in ts[1:]:
+        if t.dtype != ts[0].dtype:
+            raise RuntimeError(f'mgdt_yolo_amd: operands of one kernel must share a dtype, got {[str(u.dtype) for u in ts]}')
+
+
 def new_act(b, c, h, w, dtype, device):
     """NHWC activation buffer presented with NCHW shape semantics."""
     return torch.empty((b, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
@@ -184,6 +193,9 @@ def conv2d(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=Non
         _launch('conv2d_direct_fwd', 'mgdt_conv2d_direct_fwd', vp(x), U8 if x.dtype == torch.uint8 else dtype_code(x.dtype), ptr(pk.w), ptr(pk.bias), pk.k, stride, pk.groups, act,
                                            vp(out), dtype_code(out.dtype), stream())
     else:
+        _same(x, x2, r1, r2, out)
+        if x.dtype != pk.dtype:
+            raise RuntimeError(f'conv2d: the weights are packed for {pk.dtype}, the input is {x.dtype}')
         _launch('conv2d_fwd', 'mgdt_conv2d_fwd', vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), pk.k, stride, act,
                                     vp(r1), vp(r2), vp(out), dtype_code(pk.dtype), stream())
     return out
@@ -283,6 +295,7 @@ def csp_block(mode, x, front, front_bias, mids, shortcut, back, wd, act, cout, w
 
 def scale_channels(x, attn, out=None):
     out = like(x) if out is None else out
+    _same(x, out)
     _launch('scale_channels_fwd', 'mgdt_scale_channels_fwd', vp(x), ptr(attn), vp(out), dtype_code(x.dtype), stream())
     return out
 
@@ -293,16 +306,19 @@ def sppf_pools(x, y1, y2, y3):
 
 
 def adaptive_avgpool(x, out):
+    _same(x, out)
     _launch('adaptive_avgpool_fwd', 'mgdt_adaptive_avgpool_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def bilinear(x, out):
+    _same(x, out)
     _launch('bilinear_fwd', 'mgdt_bilinear_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def nearest(x, out):
+    _same(x, out)
     _launch('nearest_fwd', 'mgdt_nearest_fwd', vp(x), vp(out), dtype_code(x.dtype), stream())
     return out
 
@@ -456,6 +472,7 @@ def pixel_gate(x, gate, out=None):
 
 def inject(local, ga, gf, out=None):
     out = like(local) if out is None else out
+    _same(local, ga, gf, out)
     _launch('inject_fwd', 'mgdt_inject_fwd', vp(local), vp(ga), vp(gf), vp(out), dtype_code(local.dtype), stream())
     return out
 
@@ -591,6 +608,7 @@ def bn_stats(y, eps, momentum, running_mean=None, running_var=None):
 
 def bn_act(y, mean, rstd, gamma, beta, act, out=None, r1=None, r2=None):
     out = like(y) if out is None else out
+    _same(y, out, r1, r2)
     _launch('bn_act_fwd', 'mgdt_bn_act_fwd', vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, vp(r1), vp(r2), vp(out), dtype_code(y.dtype), stream())
     return out
 
@@ -598,6 +616,7 @@ def bn_act(y, mean, rstd, gamma, beta, act, out=None, r1=None, r2=None):
 def bn_act_bwd(gz, y, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None):
     """Returns dy (NHWC, same dtype); writes dgamma/dbeta (fp32) when given."""
     dy = like(y)
+    _same(gz, y)
     ws = _red_ws(y.shape[1], y.device)
     _launch('bn_act_bwd', 'mgdt_bn_act_bwd', vp(gz), vp(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(dgamma), ptr(dbeta), vp(dy), ptr(ws),
             dtype_code(y.dtype), stream())
@@ -646,6 +665,7 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
             sub = dx[:, :, ph >> 1::2, ph & 1::2]
             conv2d(dy, pks[ph], 1, ACT_NONE, out=sub, r1=sub if accumulate else None)
         return dx
+    _same(dy, dx)
     _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
     return dx
 
@@ -656,12 +676,13 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         # the 3-channel image (NCHW): one strided copy into a 4-channel NHWC buffer (4th channel zero) puts the stem on the tiled NHWC kernel;
         # the generic kernel would scan every pixel once per weight element
         b, c, h, w = x.shape
-        x4 = new_act(b, 4, h, w, torch.float32, x.device).zero_()      # a uint8 image is divided by 255 by the copy (detect/train.py:64)
+        x4 = new_act(b, 4, h, w, dy.dtype, x.device).zero_()           # in dy's dtype; a uint8 image is divided by 255 by the copy (detect/train.py:64)
         copy(x, x4[:, :c])
         dw4 = torch.empty((dw.shape[0], 4, k, k), dtype=torch.float32, device=x.device)
         conv_wgrad(x4, dy, k, stride, dw4, dbias=dbias)
         copy(dw4[:, :c], dw)
         return
+    _same(x, dy, x2)
     ws = torch.empty(lib.mgdt_conv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k), dtype=torch.uint8, device=x.device)
     if _PROF is not None:
         b, ci, h, w = x.shape
@@ -672,19 +693,22 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
 
 def add(a, b, out=None):
     out = like(a) if out is None else out
+    _same(a, b, out)
     _launch('add_fwd', 'mgdt_add_fwd', vp(a), vp(b), vp(out), dtype_code(a.dtype), stream())
     return out
 
 
 def maxpool5_bwd(x, gy):
-    """Adjoint of MaxPool2d(5,1,2): dense fp32 NHWC gradient (B,C,H,W channels_last)."""
+    """Adjoint of MaxPool2d(5,1,2): dense NHWC gradient (B,C,H,W channels_last) in the dtype of gy (computed in fp32)."""
+    _same(x, gy)
     b, c, h, w = x.shape
-    gx = torch.zeros((b, c, h, w), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    gx = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
     _launch('maxpool5_bwd', 'mgdt_maxpool5_bwd', vp(x), vp(gy), ptr(gx), dtype_code(x.dtype), stream())
-    return gx
+    return gx if gy.dtype == torch.float32 else copy(gx, like(gy))
 
 
 def nearest_bwd(gy, gx):
+    _same(gy, gx)
     _launch('nearest_bwd', 'mgdt_nearest_bwd', vp(gy), vp(gx), dtype_code(gy.dtype), stream())
     return gx
 
@@ -695,18 +719,21 @@ EW_MUL, EW_HSIG_GRAD, EW_MUL_HSIG, EW_HSIG = 0, 1, 2, 3
 
 def ew(a, b, mode, out=None):
     out = like(a) if out is None else out
+    _same(a, b, out)
     _launch('ew_binary', 'mgdt_ew_binary', vp(a), vp(b), vp(out), mode, dtype_code(a.dtype), stream())
     return out
 
 
 def channel_affine(x, scale, shift, out=None):
     out = like(x) if out is None else out
+    _same(x, out)
     _launch('channel_affine', 'mgdt_channel_affine', vp(x), ptr(scale), ptr(shift), vp(out), dtype_code(x.dtype), stream())
     return out
 
 
 def nc_reduce(a, b=None):
     """sum over (h, w) of a*b (or a) per (image, channel) -> fp32 [B, C]."""
+    _same(a, b)
     n, c = a.shape[:2]
     out = torch.empty(n, c, dtype=torch.float32, device=a.device)
     ws = torch.empty(L.lib().mgdt_nc_reduce_workspace_bytes(n, c), dtype=torch.uint8, device=a.device)
@@ -715,11 +742,13 @@ def nc_reduce(a, b=None):
 
 
 def adaptive_avgpool_bwd(gy, gx, accumulate=False):
+    _same(gy, gx)
     _launch('adaptive_avgpool_bwd', 'mgdt_adaptive_avgpool_bwd', vp(gy), vp(gx), int(accumulate), dtype_code(gy.dtype), stream())
     return gx
 
 
 def bilinear_bwd(gy, gx, accumulate=False):
+    _same(gy, gx)
     _launch('bilinear_bwd', 'mgdt_bilinear_bwd', vp(gy), vp(gx), int(accumulate), dtype_code(gy.dtype), stream())
     return gx
 
@@ -758,6 +787,7 @@ def dwconv7_ln_train(x, dw_w49c, dw_b, ln_w, ln_b, eps):
 def dwconv7_ln_bwd(x, u, gy, dw_w49c, ln_w, eps, d_dw_w, d_dw_b, d_ln_w, d_ln_b):
     c = x.shape[1]
     dx, tmp = like(x), like(x)
+    _same(x, u, gy)
     ws = torch.empty(L.lib().mgdt_dwconv7_ln_bwd_workspace_bytes(c), dtype=torch.uint8, device=x.device)
     _launch('dwconv7_ln_bwd', 'mgdt_dwconv7_ln_bwd', vp(x), vp(u), vp(gy), ptr(dw_w49c), ptr(ln_w), eps, vp(tmp), vp(dx), 0, ptr(d_dw_w), ptr(d_dw_b),
             ptr(d_ln_w), ptr(d_ln_b), ptr(ws), dtype_code(x.dtype), stream())
@@ -767,6 +797,7 @@ def dwconv7_ln_bwd(x, u, gy, dw_w49c, ln_w, eps, d_dw_w, d_dw_b, d_ln_w, d_ln_b)
 def grn_bwd(g, t, S, A, B, gamma, dgamma, dbeta):
     n, c = t.shape[:2]
     dt = like(t)
+    _same(g, t)
     ws = torch.empty(3 * n * c, dtype=torch.float32, device=t.device)
     _launch('grn_bwd', 'mgdt_grn_bwd', vp(g), vp(t), ptr(S), ptr(A), ptr(B), ptr(gamma), vp(dt), ptr(dgamma), ptr(dbeta), ptr(ws), dtype_code(t.dtype), stream())
     return dt

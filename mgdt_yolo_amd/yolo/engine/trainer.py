@@ -115,8 +115,12 @@ class DetectionTrainer:
     clip 10.0; EMA decay 0.9999, tau 2000).  `batch_size` is the GLOBAL batch (trainer.py:238,250), `nb` the batches per epoch."""
 
     def __init__(self, model, lr0=0.001, lrf=0.01, momentum=0.937, weight_decay=5e-4, world_size=1, ema_decay=0.9999, ema_tau=2000.0,
-                 batch_size=None, nb=None, epochs=100, nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, overlap=True):
+                 batch_size=None, nb=None, epochs=100, nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, overlap=True, amp=False):
         self.model = model.train()
+        # amp: the reference trains under autocast (trainer.py:223,329: fp16 + GradScaler); on this hardware the reduced-precision training path
+        # is bfloat16 activations / gradients with fp32 master weights, fp32 accumulation and fp32 weight gradients - no loss scaling needed
+        model.set_compute_dtype(torch.bfloat16 if amp else torch.float32)
+        self.amp = bool(amp)
         self.crit = v8DetectionLoss(model)
         self.world_size = world_size
         self.lr0, self.lrf, self.momentum, self.epochs = lr0, lrf, momentum, epochs
@@ -159,7 +163,7 @@ class DetectionTrainer:
         """detect/train.py:62-65 moves the uint8 batch to the device and computes float()/255; here the uint8 tensor goes to the stem
         kernel, which divides by 255 exactly while loading (no separate pass)."""
         img = batch['img'].to(self.state.data.device, non_blocking=True)
-        return img if img.dtype == torch.uint8 else img.float()
+        return img if img.dtype == torch.uint8 else (img.to(torch.bfloat16) if self.amp else img.float())
 
     def optimizer_step(self):
         """unscale (no loss scaling: fp32 / bf16) -> clip_grad_norm_(10) -> SGD -> zero_grad (implicit: overwrite) -> EMA (trainer.py:462-470)."""

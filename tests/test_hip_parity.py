@@ -1166,3 +1166,37 @@ def test_sprmodule_standalone_forward(golden):
         y = m(x)
     assert y.shape == (2, 16, 1, 1)
     np.testing.assert_allclose(y.cpu().numpy(), golden('modules')['spr'], atol=1e-5, rtol=1e-5)
+
+
+def test_bf16_training_step_tracks_the_fp32_step():
+    """amp=True (bf16 activations / activation gradients, fp32 master weights, fp32 accumulation and weight gradients) against the fp32 step on
+    the same batch.  Stated tolerance of the reduced-precision TRAINING path (the reference's fp16 AMP states none): loss within 2 %; the flat
+    gradient has cosine > 0.97 with the fp32 one and a norm within 20 %; every tensor that carries a measurable share of the gradient keeps
+    cosine > 0.7 (measured on MI355X, B=4 at 96^2 with batch-statistics BN on 3x3 maps - the noisiest setting: head 0.98-1.00, neck 0.97,
+    backbone 0.93-0.95, worst single BN scale 0.76; the error grows with the depth of the reverse pass, as rounding every activation
+    gradient to 8 mantissa bits must)."""
+    from mgdt_yolo_amd.nn.tasks import DetectionModel
+    from mgdt_yolo_amd.seeding import seeded_labels
+    from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
+    nc, B, S = 4, 4, 96
+    batch = dict(img=(seeded_images(B, S, S, seed=2) * 255).to(torch.uint8), **seeded_labels(B, nc, seed=6, max_boxes=4, min_boxes=2))
+    batch['bboxes'][:, 2:] = batch['bboxes'][:, 2:] * 0.5 + 0.1
+    res = {}
+    for amp in (False, True):
+        m = seed_state_dict_(DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', nc), verbose=False), 0).to(DEV)
+        tr = DetectionTrainer(m, lr0=0.0, amp=amp)                      # lr 0: the step leaves the weights alone, the flat gradient stays readable
+        loss, _ = tr.step(batch)
+        res[amp] = (loss.item(), tr.state.grad.clone(), dict(tr.state.offsets))
+    (l32, g32, off), (l16, g16, _) = res[False], res[True]
+    print(f'loss fp32 {l32:.4f} bf16 {l16:.4f}; |g| fp32 {g32.norm().item():.4f} bf16 {g16.norm().item():.4f}; cosine {torch.nn.functional.cosine_similarity(g32, g16, 0).item():.5f}')
+    assert abs(l16 - l32) < 0.02 * abs(l32)
+    assert abs(g16.norm().item() - g32.norm().item()) < 0.2 * g32.norm().item()
+    assert torch.nn.functional.cosine_similarity(g32, g16, 0).item() > 0.97
+    worst = []
+    for k, (o, n) in off.items():
+        a, b = g32[o:o + n], g16[o:o + n]
+        if a.norm().item() > 1e-3 * g32.norm().item():                  # tensors that carry a measurable share of the gradient
+            worst.append((torch.nn.functional.cosine_similarity(a, b, 0).item(), k))
+    worst.sort()
+    print('lowest per-tensor cosines', worst[:4])
+    assert worst[0][0] > 0.7, worst[:4]
