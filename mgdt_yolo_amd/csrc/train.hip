@@ -9,6 +9,14 @@
 #include "common.h"
 
 #define RED_SPLITS 512
+// vectorised versions for pixel-linear views (bn_fast.hip); each returns false when a view does not qualify
+bool mgdt_bnf_stats(const mgdt_view* y, double* partial, int dtype, hipStream_t st);
+bool mgdt_bnf_fwd(const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const mgdt_view* r1,
+                  const mgdt_view* r2, const mgdt_view* z, int dtype, hipStream_t st);
+bool mgdt_bnf_bwd_partial(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                          double* partial, int dtype, hipStream_t st);
+bool mgdt_bnf_bwd_apply(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                        const float* coef, const mgdt_view* dy, int dtype, hipStream_t st);
 // channel lanes of a reduction block: the whole channel range when it is narrow, so that all 256 threads have pixels to walk
 static __host__ __device__ inline int red_cw(int c) { return c > 32 ? 64 : c > 16 ? 32 : c > 8 ? 16 : c > 4 ? 8 : 4; }
 
@@ -76,12 +84,37 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const mgdt_view y
   channel_reduce<T>(y, partial, [&](long off, long, long, long, int, float& a0, float& a1) { float v = (float)p[off]; a0 = v; a1 = v * v; });
 }
 
-__global__ void bn_stats_final_kernel(const double* partial, int C, double count, float eps, float momentum, float* mean, float* rstd,
+// sum of the RED_SPLITS partial rows of 16 channels per workgroup: 16 threads per channel each add 32 rows (loads independent, in flight
+// together), thread 0 of the channel adds the 16 sub-sums in order - a fixed association, so the result does not depend on scheduling.
+// (One thread per channel walking all 512 rows was a ~100 us dependent chain per BN layer.)
+#define FIN_CW 16
+__device__ __forceinline__ bool final_sum(const double* __restrict__ partial, int C, int& c, double& s0, double& s1) {
+  __shared__ double red[2][16][FIN_CW];
+  const int cl = threadIdx.x % FIN_CW, part = threadIdx.x / FIN_CW;
+  c = blockIdx.x * FIN_CW + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    constexpr int ROWS = RED_SPLITS / 16;
+#pragma unroll 8
+    for (int k = 0; k < ROWS; ++k) {
+      const double2 v = *(const double2*)(partial + ((long)(part * ROWS + k) * C + c) * 2);
+      a0 += v.x; a1 += v.y;
+    }
+  }
+  red[0][part][cl] = a0; red[1][part][cl] = a1;
+  __syncthreads();
+  if (part != 0 || c >= C) return false;
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s0 += red[0][k][cl]; s1 += red[1][k][cl]; }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* partial, int C, double count, float eps, float momentum, float* mean, float* rstd,
                                       float* running_mean, float* running_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int k = 0; k < RED_SPLITS; ++k) { s += partial[((long)k * C + c) * 2]; ss += partial[((long)k * C + c) * 2 + 1]; }
+  int c;
+  double s, ss;
+  if (!final_sum(partial, C, c, s, ss)) return;
   double m = s / count, var = ss / count - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
@@ -93,15 +126,17 @@ __global__ void bn_stats_final_kernel(const double* partial, int C, double count
   }
 }
 
-extern "C" size_t mgdt_reduce_workspace_bytes(int c) { return ((size_t)RED_SPLITS * c * 2 + (size_t)c * 2) * sizeof(double); }   // partials + per-channel sums
+extern "C" size_t mgdt_reduce_workspace_bytes(int c) { return ((size_t)RED_SPLITS * c * 2 + (size_t)c * 2) * sizeof(double) + (size_t)c * 2 * sizeof(float); }   // partials + per-channel sums + their means
 
 extern "C" int mgdt_bn_stats_fwd(const mgdt_view* y, float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                  float* running_var, void* ws, int dtype, mgdt_stream s) {
   if (!view_ok(y) || !mean || !rstd || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_stats: null/empty argument");
   if (y->sc != 1) MGDT_FAIL(MGDT_BAD_SHAPE, "bn_stats: NHWC view required");
-  dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
-  MGDT_DISPATCH_DTYPE(dtype, (bn_stats_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*y, (double*)ws)));
-  bn_stats_final_kernel<<<cdiv(y->c, 256), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
+  if (!mgdt_bnf_stats(y, (double*)ws, dtype, (hipStream_t)s)) {
+    dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
+    MGDT_DISPATCH_DTYPE(dtype, (bn_stats_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*y, (double*)ws)));
+  }
+  bn_stats_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
                                                                      running_mean, running_var);
   MGDT_CHECK_LAUNCH("bn_stats_fwd");
   return MGDT_OK;
@@ -138,7 +173,8 @@ extern "C" int mgdt_bn_act_fwd(const mgdt_view* y, const float* mean, const floa
   if ((mean != nullptr) != (rstd != nullptr) || (mean && (!gamma || !beta))) MGDT_FAIL(MGDT_BAD_ARG, "bn_act: mean/rstd/gamma/beta must come together");
   long total = (long)y->n * y->h * y->w * y->c;
   mgdt_view a = (r1 && r1->p) ? *r1 : null_view(), b = (r2 && r2->p) ? *r2 : null_view();
-  MGDT_DISPATCH_DTYPE(dtype, (bn_act_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*y, mean, rstd, gamma, beta, act, a, b, *z)));
+  if (!mgdt_bnf_fwd(y, mean, rstd, gamma, beta, act, r1, r2, z, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (bn_act_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*y, mean, rstd, gamma, beta, act, a, b, *z)));
   MGDT_CHECK_LAUNCH("bn_act_fwd");
   return MGDT_OK;
 }
@@ -161,12 +197,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const mgdt_view gz,
 }
 
 // per-channel totals of the two BN-backward sums (+ the parameter gradients), once, instead of RED_SPLITS loads per element
-__global__ void bn_bwd_final_kernel(const double* partial, int C, double* sums, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int k = 0; k < RED_SPLITS; ++k) { sg += partial[((long)k * C + c) * 2]; sgx += partial[((long)k * C + c) * 2 + 1]; }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* partial, int C, double count, double* sums, float* coef, float* dgamma, float* dbeta) {
+  int c;
+  double sg, sgx;
+  if (!final_sum(partial, C, c, sg, sgx)) return;
   sums[2 * c] = sg; sums[2 * c + 1] = sgx;
+  coef[2 * c] = (float)(sg / count); coef[2 * c + 1] = (float)(sgx / count);     // what the apply pass subtracts, divided once
   if (dbeta) dbeta[c] = (float)sg;
   if (dgamma) dgamma[c] = (float)sgx;
 }
@@ -206,10 +242,13 @@ extern "C" int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const fl
   dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
   long total = (long)y->n * y->h * y->w * y->c;
   double* sums = (double*)ws + (size_t)RED_SPLITS * y->c * 2;
-  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (double*)ws)));
-  bn_bwd_final_kernel<<<cdiv(y->c, 256), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, sums, dgamma, dbeta);
-  MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, sums,
-                                                                                               (double)y->n * y->h * y->w, *dy)));
+  if (!mgdt_bnf_bwd_partial(gz, y, mean, rstd, gamma, beta, act, (double*)ws, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (double*)ws)));
+  float* coef = (float*)(sums + (size_t)y->c * 2);
+  bn_bwd_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, sums, coef, dgamma, dbeta);
+  if (!mgdt_bnf_bwd_apply(gz, y, mean, rstd, gamma, beta, act, coef, dy, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, sums,
+                                                                                                 (double)y->n * y->h * y->w, *dy)));
   MGDT_CHECK_LAUNCH("bn_act_bwd");
   return MGDT_OK;
 }
@@ -344,12 +383,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view
   }
 }
 
-__global__ void wgrad_final_kernel(const float* partial, long n, float* dw, int accumulate, int nsplit) {
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+// 64 weight elements per workgroup, 4 threads per element: thread `part` adds rows part, part+4, ... (independent loads, 8 in flight), then the
+// four sub-sums are added in order.  Fixed association; a single thread walking up to 256 rows was a dependent-latency chain of ~50 us.
+__global__ __launch_bounds__(256) void wgrad_final_kernel(const float* __restrict__ partial, long n, float* dw, int accumulate, int nsplit) {
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + el;
+  float a = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int k = part; k < nsplit; k += 4) a += partial[(long)k * n + i];
+  }
+  red[part][el] = a;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    const float t = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
 }
 
 template <typename T>
@@ -357,11 +407,10 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const mgdt_view 
   const T* p = (const T*)dy.p;
   channel_reduce<T>(dy, partial, [&](long off, long, long, long, int, float& a0, float& a1) { a0 = (float)p[off]; a1 = 0.f; });
 }
-__global__ void bias_grad_final_kernel(const double* partial, int C, float* db, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int k = 0; k < RED_SPLITS; ++k) s += partial[((long)k * C + c) * 2];
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const double* partial, int C, float* db, int accumulate) {
+  int c;
+  double s, unused;
+  if (!final_sum(partial, C, c, s, unused)) return;
   db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
 
@@ -407,11 +456,11 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     int nel = dy->c * x->c * k * k;
     if (dtype == MGDT_F32) conv_wgrad_generic_kernel<float, float><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
     else conv_wgrad_generic_kernel<float, bf16><<<dim3(nel, WG_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, (float*)ws, nel);
-    wgrad_final_kernel<<<cdiv(nel, 256), 256, 0, st>>>((const float*)ws, nel, dw_oihw, accumulate, WG_SPLITS);
+    wgrad_final_kernel<<<cdiv(nel, 64), 256, 0, st>>>((const float*)ws, nel, dw_oihw, accumulate, WG_SPLITS);
     if (dbias) {
       dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
       MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
-      bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
+      bias_grad_final_kernel<<<cdiv(dy->c, FIN_CW), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
     }
     MGDT_CHECK_LAUNCH("conv_wgrad(generic)");
     return MGDT_OK;
@@ -425,11 +474,11 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
   }
   long n = (long)dy->c * x->c * k * k;
-  wgrad_final_kernel<<<cdiv(n, 256), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
+  wgrad_final_kernel<<<cdiv(n, 64), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
   if (dbias) {
     dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
     MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
-    bias_grad_final_kernel<<<cdiv(dy->c, 256), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
+    bias_grad_final_kernel<<<cdiv(dy->c, FIN_CW), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
   }
   MGDT_CHECK_LAUNCH("conv_wgrad");
   return MGDT_OK;

@@ -381,14 +381,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const mgdt_view u, const mg
     part[((long)blockIdx.x * 2 + k) * C + c] = t;
   }
 }
-__global__ void colsum_kernel(const float* part, int rows, int cols, float* out0, float* out1) {
-  // part[rows][2][cols] -> out0[c] = sum rows part[r][0][c], out1[c] = sum rows part[r][1][c]
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * cols) return;
-  int k = i / cols, c = i % cols;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += part[((long)r * 2 + k) * cols + c];
-  (k == 0 ? out0 : out1)[c] = s;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int cols, float* out0, float* out1) {
+  // part[rows][2][cols] -> out0[c] = sum rows part[r][0][c], out1[c] = sum rows part[r][1][c].  16 columns per workgroup, 16 threads per column
+  // adding rows part, part+16, ... (independent loads), then the 16 sub-sums in order: fixed association, no 1024-deep dependent chain.
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, pt = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  const int k = i / cols, c = i - k * cols;
+  float a = 0.f;
+  if (i < 2 * cols) {
+#pragma unroll 8
+    for (int r = pt; r < rows; r += 16) a += part[((long)r * 2 + k) * cols + c];
+  }
+  red[pt][cl] = a;
+  __syncthreads();
+  if (pt == 0 && i < 2 * cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    (k == 0 ? out0 : out1)[c] = t;
+  }
 }
 
 // depthwise 7x7: dx = corr(du, w flipped) ; dw[tap][c] = sum_pix du[p] * x[p+tap] ; db[c] = sum du
@@ -446,7 +458,192 @@ __global__ void dw_final_kernel(const float* part, int C, float* dw_c49, float* 
   else dw_c49[(long)c * 49 + tap] = s;      // nn.Conv2d depthwise weight layout (C,1,7,7)
 }
 
-extern "C" size_t mgdt_dwconv7_ln_bwd_workspace_bytes(int c) { return (size_t)(1024 * 2 * c + DW_SPLITS * 50 * c) * sizeof(float); }
+
+// ---- channel-vectorised versions (C % 4 == 0, 8/16-byte aligned views): 4 channels per thread, 8-/16-byte accesses ----
+#define AT4(T, v, n, h, w, c) ((T*)(v).p + ((n) * (v).sn + (h) * (v).sh + (w) * (v).sw + (c)))
+// LayerNorm backward: 8 lanes per pixel, lane l owns channel quads l, l+8, ... (NQ of them, values kept in registers: one read of u and gy);
+// the dlw / dlb partial sums stay in registers across the thread's pixels and are combined once per workgroup.
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const mgdt_view u, const mgdt_view gy, const float* __restrict__ lw, float eps, const mgdt_view du,
+                                                         float* part /* [nblk][2][C] */) {
+  const int C = u.c, Q = C >> 2, l = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const long M = (long)u.n * u.h * u.w, HW = (long)u.h * u.w;
+  f32x4 wq[NQ], alw[NQ], alb[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int q = l + 8 * k;
+    wq[k] = q < Q ? *(const f32x4*)(lw + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    alw[k] = alb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float invC = 1.f / (float)C;
+  for (long m0 = blockIdx.x * 32L; m0 < M; m0 += gridDim.x * 32L) {        // uniform trip count per wave: shuffles below need all lanes
+    const long m = m0 + pl;
+    const bool ok = m < M;
+    const long mm = ok ? m : 0;
+    const long n = mm / HW, rem = mm - n * HW;
+    const int h = (int)(rem / u.w), w = (int)(rem - (long)h * u.w);
+    f32x4 uv[NQ], gv[NQ];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = l + 8 * k;
+      const bool on = ok && q < Q;
+      uv[k] = on ? load4<T>(AT4(const T, u, n, h, w, 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      gv[k] = on ? load4<T>(AT4(const T, gy, n, h, w, 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (uv[k][0] + uv[k][1]) + (uv[k][2] + uv[k][3]);
+    }
+    for (int o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * invC;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      if (l + 8 * k < Q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = uv[k][j] - mean; ss += d * d; }
+    for (int o = 1; o < 8; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.f / sqrtf(ss * invC + eps);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      if (l + 8 * k < Q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (uv[k][j] - mean) * rstd, g = gv[k][j];
+          uv[k][j] = xh;
+          alw[k][j] += g * xh;
+          alb[k][j] += g;
+          a += g * wq[k][j];
+          b += g * wq[k][j] * xh;
+        }
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = l + 8 * k;
+      if (ok && q < Q) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[k][j] * wq[k][j] - a * invC - uv[k][j] * b * invC);
+        store4<T>(AT4(T, du, n, h, w, 4 * q), o);
+      }
+    }
+  }
+  // combine the 32 pixel lanes: LDS [32][2][C] would be 24 KB at C = 96; go through it in two halves of the k index instead
+  extern __shared__ float sm[];      // [32][C]
+  for (int kk = 0; kk < 2; ++kk) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = l + 8 * k;
+      if (q < Q) *(f32x4*)(sm + (long)pl * C + 4 * q) = kk == 0 ? alw[k] : alb[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t = 0.f;
+      for (int p = 0; p < 32; ++p) t += sm[p * C + c];
+      part[((long)blockIdx.x * 2 + kk) * C + c] = t;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_dgrad_vec_kernel(const mgdt_view du, const float* __restrict__ w49c, const mgdt_view dx, int accumulate) {
+  const int Q = dx.c >> 2;
+  const long total = (long)dx.n * dx.h * dx.w * Q;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % Q);
+    long t = i / Q;
+    const int w = (int)(t % dx.w);
+    t /= dx.w;
+    const int h = (int)(t % dx.h);
+    const long n = t / dx.h;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int oy = h + 3 - ky;
+      if ((unsigned)oy >= (unsigned)du.h) continue;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ox = w + 3 - kx;
+        if ((unsigned)ox >= (unsigned)du.w) continue;
+        const f32x4 g = load4<T>(AT4(const T, du, n, oy, ox, 4 * q));
+        const f32x4 wv = *(const f32x4*)(w49c + (ky * 7 + kx) * dx.c + 4 * q);
+        acc += g * wv;
+      }
+    }
+    if (accumulate) acc += load4<T>(AT4(const T, dx, n, h, w, 4 * q));
+    store4<T>(AT4(T, dx, n, h, w, 4 * q), acc);
+  }
+}
+
+// depthwise weight gradient: block = (ky, split); thread = (channel quad, pixel lane) holds the 7 kx taps x 4 channels of its row ky in
+// registers (du read once per 7 taps), bias sum rides with ky == 0.  part[split][50][C].
+#define DWV_SPLITS 160
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_wgrad_vec_kernel(const mgdt_view x, const mgdt_view du, float* part) {
+  const int C = du.c, Q = C >> 2, ky = blockIdx.x, split = blockIdx.y;
+  const int QB = Q < 64 ? Q : 64;                       // quads per pass over the channels (grid.z covers the rest)
+  const int q = blockIdx.z * QB + threadIdx.x % QB, pl = threadIdx.x / QB, PL = 256 / QB;
+  const long M = (long)du.n * du.h * du.w, HW = (long)du.h * du.w;
+  const long p0 = split * M / DWV_SPLITS, p1 = (split + 1) * M / DWV_SPLITS;
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (q < Q && pl < PL)
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const long n = p / HW, rem = p - n * HW;
+      const int oy = (int)(rem / du.w), ox = (int)(rem - (long)oy * du.w);
+      const f32x4 g = load4<T>(AT4(const T, du, n, oy, ox, 4 * q));
+      acc[7] += g;
+      const int iy = oy + ky - 3;
+      if ((unsigned)iy >= (unsigned)x.h) continue;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = ox + kx - 3;
+        if ((unsigned)ix < (unsigned)x.w) acc[kx] += g * load4<T>(AT4(const T, x, n, iy, ix, 4 * q));
+      }
+    }
+  __shared__ float red[8][4][256];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[k][j][threadIdx.x] = acc[k][j];
+  __syncthreads();
+  // (tap k, channel) pairs of this block: 8 x 4*QB
+  for (int o = threadIdx.x; o < 8 * 4 * QB; o += 256) {
+    const int k = o / (4 * QB), cc = o - k * 4 * QB, ql = cc >> 2, j = cc & 3;
+    const int c = (blockIdx.z * QB + ql) * 4 + j;
+    if (c >= C || (k == 7 && ky != 0)) continue;
+    float t = 0.f;
+    for (int z = 0; z < PL; ++z) t += red[k][j][z * QB + ql];
+    const int tap = k == 7 ? 49 : ky * 7 + k;
+    part[((long)split * 50 + tap) * C + c] = t;
+  }
+}
+__global__ __launch_bounds__(256) void dw_final_vec_kernel(const float* __restrict__ part, int C, int nsplit, float* dw_c49, float* db) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, pt = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  const int tap = i / C, c = i - tap * C;
+  float a = 0.f;
+  if (i < 50 * C) {
+#pragma unroll 10
+    for (int k = pt; k < nsplit; k += 16) a += part[((long)k * 50 + tap) * C + c];
+  }
+  red[pt][cl] = a;
+  __syncthreads();
+  if (pt == 0 && i < 50 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) t += red[z][cl];
+    if (tap == 49) db[c] = t;
+    else dw_c49[(long)c * 49 + tap] = t;
+  }
+}
+static bool vec4_ok(const mgdt_view* v, int dtype) {
+  return v->sc == 1 && v->c % 4 == 0 && v->sw % 4 == 0 && v->sh % 4 == 0 && v->sn % 4 == 0 && (uintptr_t)v->p % (4 * dtype_size(dtype)) == 0;
+}
+
+extern "C" size_t mgdt_dwconv7_ln_bwd_workspace_bytes(int c) { return (size_t)(1024 * 2 * c + DWV_SPLITS * 50 * c) * sizeof(float); }
 // x: block input, u: dwconv output (pre-LN, saved by the forward), gy: grad of the LN output.  Produces dx (written or
 // accumulated), d dw weight (C,1,7,7), d dw bias, d ln weight/bias.  du_tmp: caller-provided NHWC scratch like u.
 extern "C" int mgdt_dwconv7_ln_bwd(const mgdt_view* x, const mgdt_view* u, const mgdt_view* gy, const float* dw_w49c, const float* ln_w, float eps,
@@ -462,9 +659,26 @@ extern "C" int mgdt_dwconv7_ln_bwd(const mgdt_view* x, const mgdt_view* u, const
   const int nblk = (int)std::min<long>((M + 3) / 4, 1024);
   float* part = (float*)ws;
   float* part2 = part + (size_t)1024 * 2 * C;
-  MGDT_DISPATCH_DTYPE(dtype, (ln_bwd_kernel<T><<<nblk, 256, (size_t)8 * C * sizeof(float), st>>>(*u, *gy, ln_w, eps, *du_tmp, part)));
-  colsum_kernel<<<cdiv(2 * C, 256), 256, 0, st>>>(part, nblk, C, d_ln_w, d_ln_b);
+  bool vec = C <= 128;
+  for (const mgdt_view* v : {x, u, gy, du_tmp, dx}) vec = vec && vec4_ok(v, dtype);
   long total = M * C;
+  if (vec) {
+    const int nb2 = (int)std::min<long>((M + 31) / 32, 1024);
+    const int nq = cdiv(C / 4, 8);
+#define LN_VEC(NQ) MGDT_DISPATCH_DTYPE(dtype, (ln_bwd_vec_kernel<T, NQ><<<nb2, 256, (size_t)32 * C * sizeof(float), st>>>(*u, *gy, ln_w, eps, *du_tmp, part)))
+    if (nq == 1) LN_VEC(1); else if (nq == 2) LN_VEC(2); else if (nq == 3) LN_VEC(3); else LN_VEC(4);
+#undef LN_VEC
+    colsum_kernel<<<cdiv(2 * C, 16), 256, 0, st>>>(part, nb2, C, d_ln_w, d_ln_b);
+    MGDT_DISPATCH_DTYPE(dtype, (dwconv7_dgrad_vec_kernel<T><<<ew_grid(total / 4), 256, 0, st>>>(*du_tmp, dw_w49c, *dx, accumulate_dx)));
+    const int qb = std::min(C / 4, 64);
+    dim3 g(7, DWV_SPLITS, cdiv(C / 4, qb));
+    MGDT_DISPATCH_DTYPE(dtype, (dwconv7_wgrad_vec_kernel<T><<<g, 256, 0, st>>>(*x, *du_tmp, part2)));
+    dw_final_vec_kernel<<<cdiv(50 * C, 16), 256, 0, st>>>(part2, C, DWV_SPLITS, d_dw_w, d_dw_b);
+    MGDT_CHECK_LAUNCH("dwconv7_ln_bwd");
+    return MGDT_OK;
+  }
+  MGDT_DISPATCH_DTYPE(dtype, (ln_bwd_kernel<T><<<nblk, 256, (size_t)8 * C * sizeof(float), st>>>(*u, *gy, ln_w, eps, *du_tmp, part)));
+  colsum_kernel<<<cdiv(2 * C, 16), 256, 0, st>>>(part, nblk, C, d_ln_w, d_ln_b);
   MGDT_DISPATCH_DTYPE(dtype, (dwconv7_dgrad_kernel<T><<<ew_grid(total), 256, 0, st>>>(*du_tmp, dw_w49c, *dx, accumulate_dx)));
   dim3 g(50, DW_SPLITS, cdiv(C, 64));
   MGDT_DISPATCH_DTYPE(dtype, (dwconv7_wgrad_kernel<T><<<g, 256, 0, st>>>(*x, *du_tmp, part2)));
