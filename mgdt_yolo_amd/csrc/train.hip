@@ -9,6 +9,10 @@
 #include "common.h"
 
 #define RED_SPLITS 512
+
+// channel-vectorised forms (train_vec.hip); false -> run the scalar kernel
+bool mgdt_v4_add(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, hipStream_t st);
+bool mgdt_v4_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, hipStream_t st);
 // vectorised versions for pixel-linear views (bn_fast.hip); each returns false when a view does not qualify
 bool mgdt_bnf_stats(const mgdt_view* y, double* partial, int dtype, hipStream_t st);
 bool mgdt_bnf_fwd(const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const mgdt_view* r1,
@@ -505,7 +509,8 @@ extern "C" int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_v
   if (a->n != o->n || a->h != o->h || a->w != o->w || a->c != o->c || b->n != o->n || b->h != o->h || b->w != o->w || b->c != o->c)
     MGDT_FAIL(MGDT_BAD_SHAPE, "add: shape mismatch");
   long total = (long)o->n * o->h * o->w * o->c;
-  MGDT_DISPATCH_DTYPE(dtype, (add_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*a, *b, *o)));
+  if (!mgdt_v4_add(a, b, o, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (add_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*a, *b, *o)));
   MGDT_CHECK_LAUNCH("add_fwd");
   return MGDT_OK;
 }
@@ -556,7 +561,8 @@ extern "C" int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float*
   if (!view_ok(x) || !view_ok(gy) || !gx_f32) MGDT_FAIL(MGDT_BAD_ARG, "maxpool5_bwd: null/empty argument");
   if (x->sc != 1 || gy->sc != 1 || x->n != gy->n || x->h != gy->h || x->w != gy->w || x->c != gy->c) MGDT_FAIL(MGDT_BAD_SHAPE, "maxpool5_bwd: matching NHWC views");
   long total = (long)x->n * x->h * x->w * x->c;
-  MGDT_DISPATCH_DTYPE(dtype, (maxpool5_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*x, *gy, gx_f32)));
+  if (!mgdt_v4_maxpool5_bwd(x, gy, gx_f32, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (maxpool5_bwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*x, *gy, gx_f32)));
   MGDT_CHECK_LAUNCH("maxpool5_bwd");
   return MGDT_OK;
 }

@@ -3,6 +3,15 @@
 #include "common.h"
 
 #define NC_SPLITS 16
+
+// channel-vectorised forms (train_vec.hip); false -> run the scalar kernel
+bool mgdt_v4_ew_binary(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int mode, int dtype, hipStream_t st);
+bool mgdt_v4_channel_affine(const mgdt_view* x, const float* scale, const float* shift, const mgdt_view* y, int dtype, hipStream_t st);
+bool mgdt_v4_avgpool_bwd(const mgdt_view* gy, const mgdt_view* gx, int accumulate, int dtype, hipStream_t st);
+bool mgdt_v4_bilinear_bwd(const mgdt_view* gy, const mgdt_view* gx, int accumulate, int dtype, hipStream_t st);
+bool mgdt_v4_grn_bwd_apply(const mgdt_view* g, const mgdt_view* t, const float* scale, const float* coef, const mgdt_view* dt, int dtype, hipStream_t st);
+bool mgdt_v4_spr_out_bwd(const mgdt_view* gy, const float* attn, const float* dpooled, const mgdt_view* gx, int dtype, hipStream_t st);
+bool mgdt_v4_nc_reduce_partial(const mgdt_view* a, const mgdt_view* b, float* partial, int nsplit, int dtype, hipStream_t st);
 static inline int ew_grid(long total) { return (int)std::min<long>((total + 255) / 256, 16384); }
 __device__ __forceinline__ int bin_start(int o, int isz, int osz) { return (int)(((long)o * isz) / osz); }
 __device__ __forceinline__ int bin_end(int o, int isz, int osz) { return (int)(((long)(o + 1) * isz + osz - 1) / osz); }
@@ -37,7 +46,8 @@ extern "C" int mgdt_ew_binary(const mgdt_view* a, const mgdt_view* b, const mgdt
   if (a->sc != 1 || b->sc != 1 || o->sc != 1 || a->n != o->n || a->h != o->h || a->w != o->w || a->c != o->c || b->n != o->n || b->h != o->h || b->w != o->w || b->c != o->c)
     MGDT_FAIL(MGDT_BAD_SHAPE, "ew_binary: matching NHWC views");
   long total = (long)o->n * o->h * o->w * o->c;
-  MGDT_DISPATCH_DTYPE(dtype, (ew_binary_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*a, *b, *o, mode)));
+  if (!mgdt_v4_ew_binary(a, b, o, mode, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (ew_binary_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*a, *b, *o, mode)));
   MGDT_CHECK_LAUNCH("ew_binary");
   return MGDT_OK;
 }
@@ -58,7 +68,8 @@ extern "C" int mgdt_channel_affine(const mgdt_view* x, const float* scale, const
   if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "channel_affine: null/empty view");
   if (x->sc != 1 || y->sc != 1 || x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "channel_affine: matching NHWC views");
   long total = (long)x->n * x->h * x->w * x->c;
-  MGDT_DISPATCH_DTYPE(dtype, (channel_affine_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*x, scale, shift, *y)));
+  if (!mgdt_v4_channel_affine(x, scale, shift, y, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (channel_affine_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*x, scale, shift, *y)));
   MGDT_CHECK_LAUNCH("channel_affine");
   return MGDT_OK;
 }
@@ -101,7 +112,8 @@ extern "C" int mgdt_nc_reduce(const mgdt_view* a, const mgdt_view* b, float* out
   memset(&bb, 0, sizeof(bb));
   if (b && b->p) bb = *b;
   dim3 grid(a->n, NC_SPLITS, cdiv(a->c, 64));
-  MGDT_DISPATCH_DTYPE(dtype, (nc_reduce_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*a, bb, (float*)ws)));
+  if (!mgdt_v4_nc_reduce_partial(a, b, (float*)ws, NC_SPLITS, dtype, (hipStream_t)s))
+    MGDT_DISPATCH_DTYPE(dtype, (nc_reduce_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*a, bb, (float*)ws)));
   nc_reduce_final_kernel<<<cdiv((long)a->n * a->c, 256), 256, 0, (hipStream_t)s>>>((const float*)ws, a->n, a->c, out);
   MGDT_CHECK_LAUNCH("nc_reduce");
   return MGDT_OK;
@@ -168,17 +180,18 @@ __global__ void bilinear_bwd_kernel(const mgdt_view gy, const mgdt_view gx, int 
   }
 }
 
-#define RESAMPLE_BWD(fname, kern, label)                                                                                  \
+#define RESAMPLE_BWD(fname, kern, vkern, label)                                                                                  \
   extern "C" int fname(const mgdt_view* gy, const mgdt_view* gx, int accumulate, int dtype, mgdt_stream s) {              \
     if (!view_ok(gy) || !view_ok(gx)) MGDT_FAIL(MGDT_BAD_ARG, label ": null/empty view");                                 \
     if (gy->sc != 1 || gx->sc != 1 || gy->n != gx->n || gy->c != gx->c) MGDT_FAIL(MGDT_BAD_SHAPE, label ": NHWC views, same n/c"); \
     long total = (long)gx->n * gx->h * gx->w * gx->c;                                                                     \
-    MGDT_DISPATCH_DTYPE(dtype, (kern<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gy, *gx, accumulate)));              \
+    if (!vkern(gy, gx, accumulate, dtype, (hipStream_t)s))                                                               \
+      MGDT_DISPATCH_DTYPE(dtype, (kern<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gy, *gx, accumulate)));            \
     MGDT_CHECK_LAUNCH(label);                                                                                             \
     return MGDT_OK;                                                                                                       \
   }
-RESAMPLE_BWD(mgdt_adaptive_avgpool_bwd, avgpool_bwd_kernel, "adaptive_avgpool_bwd")
-RESAMPLE_BWD(mgdt_bilinear_bwd, bilinear_bwd_kernel, "bilinear_bwd")
+RESAMPLE_BWD(mgdt_adaptive_avgpool_bwd, avgpool_bwd_kernel, mgdt_v4_avgpool_bwd, "adaptive_avgpool_bwd")
+RESAMPLE_BWD(mgdt_bilinear_bwd, bilinear_bwd_kernel, mgdt_v4_bilinear_bwd, "bilinear_bwd")
 
 // ------------------------------------------------------------------------------------------------ SPR attention backward
 // forward (per image, per group gi): v = [pool1(c)] ++ [pool2(c,bin)]; hdn = relu(W1 v + b1); o = sigmoid(W2 hdn + b2);
@@ -332,7 +345,8 @@ extern "C" int mgdt_spr_bwd(const mgdt_view* gy, const float* pooled_partial, in
   spr_attn_bwd_kernel<<<N, 256, lds, st>>>(pooled_partial, fc1_w, fc1_b, fc2_w, fc2_b, C, groups, gx->h, gx->w, splits, dattn, dpooled, pimg);
   spr_param_reduce_kernel<<<cdiv(P, 256), 256, 0, st>>>(pimg, N, P, param_grads);
   long total = (long)N * gx->h * gx->w * C;
-  MGDT_DISPATCH_DTYPE(dtype, (spr_out_bwd_kernel<T><<<ew_grid(total), 256, 0, st>>>(*gy, attn, dpooled, *gx)));
+  if (!mgdt_v4_spr_out_bwd(gy, attn, dpooled, gx, dtype, st))
+    MGDT_DISPATCH_DTYPE(dtype, (spr_out_bwd_kernel<T><<<ew_grid(total), 256, 0, st>>>(*gy, attn, dpooled, *gx)));
   MGDT_CHECK_LAUNCH("spr_bwd");
   return MGDT_OK;
 }
@@ -755,7 +769,8 @@ extern "C" int mgdt_grn_bwd(const mgdt_view* g, const mgdt_view* t, const float*
   grn_bwd_small_kernel<<<N, 256, 0, st>>>(S, A, gamma, C, scale, coef, nxa);
   rowsum2_kernel<<<cdiv(C, 256), 256, 0, st>>>(nxa, B, N, C, dgamma, dbeta);
   long total = (long)N * t->h * t->w * C;
-  MGDT_DISPATCH_DTYPE(dtype, (grn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, st>>>(*g, *t, scale, coef, *dt)));
+  if (!mgdt_v4_grn_bwd_apply(g, t, scale, coef, dt, dtype, st))
+    MGDT_DISPATCH_DTYPE(dtype, (grn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, st>>>(*g, *t, scale, coef, *dt)));
   MGDT_CHECK_LAUNCH("grn_bwd");
   return MGDT_OK;
 }
