@@ -11,6 +11,7 @@
 #define RED_SPLITS 512
 
 // channel-vectorised forms (train_vec.hip); false -> run the scalar kernel
+bool mgdt_wgrad_bf16_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* partial, int nsplit, hipStream_t st);
 bool mgdt_v4_add(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, hipStream_t st);
 bool mgdt_v4_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, hipStream_t st);
 // vectorised versions for pixel-linear views (bn_fast.hip); each returns false when a view does not qualify
@@ -473,7 +474,9 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
   const int nsplit = wgrad_splits(x->c, dy->c, k);
   if ((long)dy->n * dy->h * dy->w >= 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: too many pixels");
   static const bool no_mfma = getenv("MGDT_WGRAD_VALU") != nullptr;     // experiment knob: the VALU outer-product kernel
-  if (no_mfma || !mgdt_wgrad_mfma_launch(x, x2, dy, k, stride, (float*)ws, nsplit, dtype, st)) {
+  static const bool no_bf16 = getenv("MGDT_WGRAD_F32MFMA") != nullptr;   // experiment knob: fp32 MFMA for bf16 tensors too
+  if (!no_mfma && !no_bf16 && dtype == MGDT_BF16 && mgdt_wgrad_bf16_launch(x, x2, dy, k, stride, (float*)ws, nsplit, st)) {
+  } else if (no_mfma || !mgdt_wgrad_mfma_launch(x, x2, dy, k, stride, (float*)ws, nsplit, dtype, st)) {
     dim3 grid(cdiv(dy->c, 16), cdiv(x->c, 16), k * k * nsplit);
     MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
   }

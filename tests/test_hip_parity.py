@@ -1200,3 +1200,47 @@ def test_bf16_training_step_tracks_the_fp32_step():
     worst.sort()
     print('lowest per-tensor cosines', worst[:4])
     assert worst[0][0] > 0.7, worst[:4]
+
+
+WGRAD_BF16_CASES = [  # (B, cin, cout, H, W, k, stride, x2, sliced views)
+    (2, 8, 8, 16, 16, 3, 1, False, False), (2, 16, 16, 24, 20, 3, 1, True, False), (3, 32, 32, 20, 20, 3, 1, False, True),
+    (2, 80, 80, 16, 24, 3, 1, False, False), (2, 64, 80, 9, 13, 3, 1, False, False), (2, 16, 32, 32, 32, 3, 2, False, False),
+    (2, 64, 128, 18, 22, 3, 2, False, True), (2, 384, 96, 16, 16, 1, 1, False, False), (2, 96, 384, 12, 20, 1, 1, False, False),
+    (2, 8, 8, 16, 16, 1, 1, False, True), (2, 48, 24, 10, 10, 1, 1, False, False), (1, 128, 64, 8, 8, 3, 1, True, True),
+    (4, 16, 16, 12, 12, 3, 1, True, True), (4, 32, 16, 12, 12, 3, 1, False, False), (4, 16, 32, 12, 12, 1, 1, False, False), (4, 32, 32, 6, 6, 3, 2, False, False),
+    (2, 480, 96, 8, 8, 1, 1, False, False), (2, 24, 40, 16, 16, 3, 1, False, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', WGRAD_BF16_CASES, ids=[f'{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}s{c[6]}{"_x2" if c[7] else ""}{"_view" if c[8] else ""}' for c in WGRAD_BF16_CASES])
+def test_bf16_mfma_weight_gradient(case):
+    """Weight gradient of the bf16 training path (ds_read_b64_tr_b16 + v_mfma_f32_16x16x32_bf16, wgrad_bf16.hip) against torch's fp64
+    conv2d weight gradient of the SAME bf16-rounded tensors: the products are exact and the accumulation fp32, so the only difference is
+    summation order -> relative error of the whole tensor below 2e-5, every element within 1e-3 of the largest.  Covers channel counts
+    below / at / not a multiple of the 16-wide MFMA block, maps that do not fill the 8x8 pixel tiles, stride 2, the fused x + x2 input and
+    channel-slice views of larger buffers (the concat layouts of the C2f blocks)."""
+    from mgdt_yolo_amd import ops
+    B, ci, co, H, W, k, s, with_x2, view = case
+    gen = torch.Generator().manual_seed(ci * 7 + co)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+
+    def mk(c, h, w):
+        t = torch.randn(B, c, h, w, generator=gen).to(DEV).to(torch.bfloat16)
+        if not view:
+            return t.contiguous(memory_format=torch.channels_last)
+        big = torch.zeros(B, c + 16, h, w, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        big[:, 8:8 + c] = t
+        return big[:, 8:8 + c]
+    x, dy = mk(ci, H, W), mk(co, Ho, Wo)
+    x2 = mk(ci, H, W) if with_x2 else None
+    dw = torch.full((co, ci, k, k), float('nan'), device=DEV)
+    db = torch.full((co,), float('nan'), device=DEV)
+    ops.conv_wgrad(x, dy, k, s, dw, dbias=db, x2=x2)
+    xin = x if x2 is None else (x.float() + x2.float()).to(torch.bfloat16)           # the forward's rounded pre-add
+    ref = torch.nn.grad.conv2d_weight(xin.double().contiguous(), (co, ci, k, k), dy.double().contiguous(), stride=s, padding=k // 2)
+    err = (dw.double() - ref).abs()
+    assert torch.isfinite(dw).all()
+    assert (err.norm() / ref.norm()).item() < 2e-5, (err.norm() / ref.norm()).item()
+    assert err.max().item() < 1e-3 * ref.abs().max().item()
+    assert torch.allclose(db.double(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
