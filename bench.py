@@ -227,7 +227,9 @@ def main():
         nc = 80
         cfg = get_config(args.model, args.scale, nc)
         model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).to(dev)
-        tr = DetectionTrainer(model, world_size=world, amp=args.dtype == 'bf16')      # bf16: activations / activation gradients in bf16, fp32 masters
+        # bf16: activations / activation gradients in bf16, fp32 masters.  Single rank: the step is captured in a hipGraph after the first optimizer step
+        tr = DetectionTrainer(model, world_size=world, amp=args.dtype == 'bf16', graph=not args.no_graph and world == 1)
+        graph_used = tr.graph
         R = max(1, min(args.resident, 4))
         batches = []
         for r in range(R):
@@ -240,12 +242,16 @@ def main():
             tr.step(batches[it[0] % R])
             it[0] += 1
 
-        def step_eager():
-            run()
+        def step_eager():               # instrumented pass: per-launch events need the launches themselves
+            g, tr.graph = tr.graph, False
+            try:
+                run()
+            finally:
+                tr.graph = g
         x_desc = 'uint8 NCHW images resident in HBM (/255 fused into the stem), synthetic labels (1-20 boxes / image)'
         workload = (f'{args.model}-{args.scale} (nc=80) {args.imgsz}x{args.imgsz} TRAINING step, batch {args.batch}/GPU (global {world * args.batch}): '
                     'train-mode forward (batch-stat BN) + fused assigner/loss + HIP reverse pass + bucketed RCCL all-reduce of the flat gradient buffer '
-                    '+ clip/SGD(nesterov)/EMA; BASELINE configs[2]')
+                    '+ clip/SGD(nesterov)/EMA' + ('; whole step replayed as one hipGraph' if graph_used else '') + '; BASELINE configs[2]')
         metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, data-parallel training step'
         parallelism = f'dp{world} (batch-sharded, one flat-gradient all-reduce per step over RCCL/xGMI)' if world > 1 else 'dp1 (no collective)'
         n_det = None

@@ -246,6 +246,12 @@ int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* strides, in
                          const float* gt, int n_gt, int call_count, float gain_box, float gain_cls, float gain_dfl,
                          float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
                          size_t ws_bytes, int dtype, mgdt_stream s);
+/* The same with the per-call counter in device memory (a training step captured in a hipGraph; the host advances the counter between
+ * replays).  Reference: the `epoch` argument of TaskAlignedAssigner.forward, yolo/utils/loss.py:195-206, tal.py:110,266-267. */
+int mgdt_detect_loss_fwd_dev(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
+                             const float* gt, int n_gt, const int32_t* call_count_dev, float gain_box, float gain_cls, float gain_dfl,
+                             float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
+                             size_t ws_bytes, int dtype, mgdt_stream s);
 int mgdt_detect_loss_bwd(const mgdt_view* const* feats, const mgdt_view* const* grads, const float* strides, int n_levels,
                          int reg_max, int nc, const float* gt, int n_gt, float gain_box, float gain_cls, float gain_dfl,
                          float gscale, const float* out5, void* ws, size_t ws_bytes, int dtype, mgdt_stream s);
@@ -299,6 +305,10 @@ int mgdt_grad_clip_coef(const float* g, long n, float max_norm, float* out2, voi
 int mgdt_sgd_step(float* p, const float* g, float* buf, const float* wd, long n, float lr, float lr_bias, float momentum, int nesterov,
                   int first, const float* clip2, mgdt_stream s);
 int mgdt_ema_update(float* ema, const float* p, long n, float decay, mgdt_stream s);
+/* SGD + EMA in one launch, scalars from device memory: hyper4 = {lr, lr_bias, momentum, ema_decay}; [0, n_param) parameters, [n_param, n_total)
+ * buffers (EMA only; ema may be NULL).  Reference: yolo/engine/trainer.py:317-326 (warm-up values), :462-470, yolo/utils/torch_utils.py:342. */
+int mgdt_sgd_ema_step_dev(float* p, const float* g, float* buf, const float* wd, long n_param, float* ema, long n_total, const float* hyper4,
+                          int nesterov, int first, const float* clip2, mgdt_stream s);
 
 /* ---- box helpers, validator reductions, predictor preprocess; fp32 boxes, rows of `row` >= 4 floats ------------
  * box_convert: mode 0 = xywh2xyxy (yolo/utils/ops.py:362-377), 1 = xyxy2xywh (:345-359); columns >= 4 are copied.

@@ -71,6 +71,7 @@ PROTOTYPES = {
     'mgdt_detect_decode_fwd': (_i, [VP, _i, _i, _f, _i, _i, _vp, _i, _vp]),
     'mgdt_detect_loss_workspace_bytes': (_sz, [_i, _i, _i]),
     'mgdt_detect_loss_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    'mgdt_detect_loss_fwd_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     'mgdt_detect_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _vp, _vp, _sz, _i, _vp]),
     'mgdt_reduce_workspace_bytes': (_sz, [_i]),
     'mgdt_bn_stats_fwd': (_i, [VP, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -98,6 +99,7 @@ PROTOTYPES = {
     'mgdt_grad_clip_coef': (_i, [_vp, C.c_long, _f, _vp, _vp, _vp]),
     'mgdt_sgd_step': (_i, [_vp, _vp, _vp, _vp, C.c_long, _f, _f, _f, _i, _i, _vp, _vp]),
     'mgdt_ema_update': (_i, [_vp, _vp, C.c_long, _f, _vp]),
+    'mgdt_sgd_ema_step_dev': (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, C.c_long, _vp, _i, _i, _vp, _vp]),
     'mgdt_box_convert': (_i, [_vp, _vp, C.c_long, _i, _i, _vp]),
     'mgdt_box_iou': (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     'mgdt_bbox_iou': (_i, [_vp, _i, _vp, _i, C.c_long, _i, _i, _f, _vp, _vp]),

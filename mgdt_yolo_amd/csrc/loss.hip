@@ -26,6 +26,7 @@ struct LossArgs {
   const float* gt;           // [B][N][5] = cls, x1, y1, x2, y2 (pixels); rows with box sum <= 0 are padding
   int N;
   float alpha, beta;
+  const int* call_dev;       // when set: the per-call counter lives on the device (captured training step), alpha is derived from it
   float* pbox;               // [B][A][4] predicted xyxy, grid units
   float* anc;                // [A][3]    anchor x, y (grid units), stride
   float* align;              // [B][N][A]
@@ -140,7 +141,8 @@ __global__ void tal_metrics_kernel(const LossArgs a) {
     int label = (int)g[0];
     const T* p = (const T*)a.feat + b * a.fsn + oy * a.fsh + ox * a.fsw;
     float sc = sigmoidf_((float)p[4 * a.R + label]);
-    al_v = powf(sc, a.alpha) * powf(ov_v, a.beta);
+    const float alpha = a.call_dev ? 0.5f * (float)(100 - *a.call_dev / 161) / 100.f : a.alpha;
+    al_v = powf(sc, alpha) * powf(ov_v, a.beta);
   }
   long o = ((long)b * a.N + j) * a.A + ag;
   a.align[o] = al_v;
@@ -363,10 +365,10 @@ extern "C" size_t mgdt_detect_loss_workspace_bytes(int b, int a_total, int n_gt)
   return f * 4 + i * 4 + ((u + 15) & ~(size_t)15) + 256;
 }
 
-extern "C" int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
-                                    const float* gt, int n_gt, int call_count, float gain_box, float gain_cls, float gain_dfl,
-                                    float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
-                                    size_t ws_bytes, int dtype, mgdt_stream s) {
+static int detect_loss_fwd_impl(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
+                                const float* gt, int n_gt, int call_count, const int32_t* call_count_dev, float gain_box, float gain_cls, float gain_dfl,
+                                float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
+                                size_t ws_bytes, int dtype, mgdt_stream s) {
   if (!feats || !strides || n_levels < 1 || n_levels > 8 || !out5 || !ws) MGDT_FAIL(MGDT_BAD_ARG, "detect_loss: null/empty argument");
   if (n_gt > 0 && !gt) MGDT_FAIL(MGDT_BAD_ARG, "detect_loss: gt is NULL");
   const int B = feats[0]->n, no = 4 * reg_max + nc;
@@ -384,6 +386,7 @@ extern "C" int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* 
   // alpha schedule of the fork: coff = call_count // 161, alpha = 0.5 * (100 - coff) / 100 (tal.py:110,266-267); beta = 8 (loss.py:125-126)
   a.alpha = 0.5f * (float)(100 - call_count / 161) / 100.f;
   a.beta = 8.0f;
+  a.call_dev = call_count_dev;
   a.gain_box = gain_box; a.gain_cls = gain_cls; a.gain_dfl = gain_dfl;
   float* f = (float*)ws;
   a.pbox = f; f += (size_t)B * A * 4;
@@ -440,6 +443,24 @@ extern "C" int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* 
   if (tscore_out) hipMemcpyAsync(tscore_out, a.tscore, (size_t)B * A * 4, hipMemcpyDeviceToDevice, st);
   MGDT_CHECK_LAUNCH("detect_loss_fwd");
   return MGDT_OK;
+}
+
+extern "C" int mgdt_detect_loss_fwd(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
+                                    const float* gt, int n_gt, int call_count, float gain_box, float gain_cls, float gain_dfl,
+                                    float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
+                                    size_t ws_bytes, int dtype, mgdt_stream s) {
+  return detect_loss_fwd_impl(feats, strides, n_levels, reg_max, nc, gt, n_gt, call_count, nullptr, gain_box, gain_cls, gain_dfl, out5, fg_out, gt_idx_out,
+                              tscore_out, ws, ws_bytes, dtype, s);
+}
+// Same, with the per-call counter of the assigner's alpha schedule read from device memory: a captured (hipGraph) training step replays
+// with a counter the host advances between replays.
+extern "C" int mgdt_detect_loss_fwd_dev(const mgdt_view* const* feats, const float* strides, int n_levels, int reg_max, int nc,
+                                        const float* gt, int n_gt, const int32_t* call_count_dev, float gain_box, float gain_cls, float gain_dfl,
+                                        float* out5, unsigned char* fg_out, int32_t* gt_idx_out, float* tscore_out, void* ws,
+                                        size_t ws_bytes, int dtype, mgdt_stream s) {
+  if (!call_count_dev) MGDT_FAIL(MGDT_BAD_ARG, "detect_loss_fwd_dev: call_count_dev is NULL");
+  return detect_loss_fwd_impl(feats, strides, n_levels, reg_max, nc, gt, n_gt, 0, call_count_dev, gain_box, gain_cls, gain_dfl, out5, fg_out, gt_idx_out,
+                              tscore_out, ws, ws_bytes, dtype, s);
 }
 
 // grad_feats[l] = gscale * d(total)/d feats[l]; must follow mgdt_detect_loss_fwd with the SAME ws / out5 / arguments.

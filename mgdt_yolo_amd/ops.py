@@ -549,7 +549,7 @@ class DetectLossState:
     __slots__ = ('feats', 'strides', 'gt', 'n_gt', 'out5', 'ws', 'ws_bytes', 'reg_max', 'nc', 'gains', 'fg', 'gt_idx', 'tscore')
 
 
-def detect_loss_fwd(feats, strides, reg_max, nc, gt, call_count, gains, want_assignment=False):
+def detect_loss_fwd(feats, strides, reg_max, nc, gt, call_count, gains, want_assignment=False, call_count_dev=None):
     """feats: list of (B, 4R+nc, H, W) NHWC tensors; gt: (B, N, 5) fp32 cuda [cls, x1, y1, x2, y2] px.  Returns DetectLossState."""
     lib = L.lib()
     for f in feats:
@@ -572,6 +572,11 @@ def detect_loss_fwd(feats, strides, reg_max, nc, gt, call_count, gains, want_ass
     st.tscore = torch.empty(b, a_total, dtype=torch.float32, device=dev) if want_assignment else None
     arr, keep = _view_array(feats)
     sarr = (C.c_float * len(feats))(*st.strides.tolist())
+    if call_count_dev is not None:              # int32[1] on the device: the captured training step (hipGraph) replays with the host's counter
+        _launch('detect_loss_fwd', 'mgdt_detect_loss_fwd_dev', arr, sarr, len(feats), reg_max, nc, ptr(st.gt) if n_gt else None, n_gt, ptr(call_count_dev),
+                float(gains[0]), float(gains[1]), float(gains[2]), ptr(st.out5), ptr(st.fg), ptr(st.gt_idx), ptr(st.tscore), ptr(st.ws), st.ws_bytes,
+                dtype_code(feats[0].dtype), stream())
+        return st
     _launch('detect_loss_fwd', 'mgdt_detect_loss_fwd', arr, sarr, len(feats), reg_max, nc, ptr(st.gt) if n_gt else None, n_gt, int(call_count),
             float(gains[0]), float(gains[1]), float(gains[2]), ptr(st.out5), ptr(st.fg), ptr(st.gt_idx), ptr(st.tscore), ptr(st.ws), st.ws_bytes,
             dtype_code(feats[0].dtype), stream())
@@ -820,6 +825,14 @@ PARAM_EPOCH = [0]
 def sgd_step(p, g, buf, wd, lr, momentum, nesterov, first, clip=None, lr_bias=None):
     PARAM_EPOCH[0] += 1
     _launch('sgd_step', 'mgdt_sgd_step', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), float(lr), float(lr if lr_bias is None else lr_bias), float(momentum),
+            int(nesterov), int(first), ptr(clip), stream())
+
+
+def sgd_ema_step_dev(p, g, buf, wd, ema, data, hyper, nesterov, first, clip=None):
+    """SGD over the parameters `p` (= data[:p.numel()]) and EMA over all of `data`, scalars {lr, lr_bias, momentum, ema_decay} from the device
+    tensor `hyper` (fp32[4]): the form a captured training step uses."""
+    PARAM_EPOCH[0] += 1
+    _launch('sgd_ema_step_dev', 'mgdt_sgd_ema_step_dev', ptr(p), ptr(g), ptr(buf), ptr(wd), p.numel(), ptr(ema), data.numel(), ptr(hyper),
             int(nesterov), int(first), ptr(clip), stream())
 
 

@@ -115,7 +115,8 @@ class DetectionTrainer:
     clip 10.0; EMA decay 0.9999, tau 2000).  `batch_size` is the GLOBAL batch (trainer.py:238,250), `nb` the batches per epoch."""
 
     def __init__(self, model, lr0=0.001, lrf=0.01, momentum=0.937, weight_decay=5e-4, world_size=1, ema_decay=0.9999, ema_tau=2000.0,
-                 batch_size=None, nb=None, epochs=100, nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, overlap=True, amp=False):
+                 batch_size=None, nb=None, epochs=100, nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, overlap=True, amp=False,
+                 graph=False):
         self.model = model.train()
         # amp: the reference trains under autocast (trainer.py:223,329: fp16 + GradScaler); on this hardware the reduced-precision training path
         # is bfloat16 activations / gradients with fp32 master weights, fp32 accumulation and fp32 weight gradients - no loss scaling needed
@@ -136,6 +137,11 @@ class DetectionTrainer:
         model._flat_state = self.state
         self.ema_decay, self.ema_tau = ema_decay, ema_tau
         self.ni, self.last_opt_step, self.lr, self.lr_bias, self.mom = 0, -1, lr0, lr0, momentum
+        # graph=True: from the second optimizer step on, the whole step (forward, loss, reverse pass, clip + SGD + EMA: ~500 launches) is one
+        # hipGraph replay; lr / momentum / EMA decay / the assigner's call counter live in device memory so that the warm-up schedule and the
+        # EMA ramp keep advancing between replays.  Single-rank, accumulate == 1 only (otherwise the eager path runs).
+        self.graph = bool(graph)
+        self._graphs, self._pool, self._static = {}, None, None
         self.exchange = None
         if parallel.world() > 1:
             parallel.broadcast_(self.state.data)            # what DDP's constructor does (trainer.py:225): rank 0's parameters AND buffers
@@ -174,9 +180,65 @@ class DetectionTrainer:
         d = self.ema_decay * (1 - math.exp(-st.steps / self.ema_tau))      # torch_utils.py:342
         ops.ema_update(st.ema, st.data, d)
 
+    # ---- captured step -------------------------------------------------------------------------------------------------------------
+    def _graph_ok(self):
+        return (self.graph and parallel.world() == 1 and self.state.steps >= 1 and self.accumulate == 1
+                and (self.batch_size is None or self.nbs / self.batch_size <= 1.0))
+
+    def _graph_body(self):
+        st, S = self.state, self._static
+        feats = self.model._predict_once(S['img'])
+        ls = ops.detect_loss_fwd(list(feats), self.crit.stride_list, self.crit.reg_max, self.crit.nc, S['gt'], 0,
+                                 (self.crit.hyp.box, self.crit.hyp.cls, self.crit.hyp.dfl), call_count_dev=S['calls'])
+        grads = ops.detect_loss_bwd(ls, float(self.world_size))
+        self.model.backward(grads)
+        clip = ops.grad_clip_coef(st.grad, 10.0)
+        ops.sgd_ema_step_dev(st.data[:st.n_param], st.grad, st.momentum_buf, st.wd, st.ema, st.data, S['hyper'], True, False, clip)
+        S['out5'] = ls.out5
+
+    def _graph_step(self, batch):
+        st = self.state
+        img = self.preprocess_batch(batch)
+        b = img.shape[0]
+        gt = self.crit.preprocess(batch, b, (img.shape[2], img.shape[3]))
+        nmax = max(16, -(-int(gt.shape[1]) // 16) * 16)             # label slots of the captured step (zero rows are padding, loss.py:177-181)
+        S = self._static
+        if S is None or S['img'].shape != img.shape or S['img'].dtype != img.dtype:
+            S = self._static = dict(img=torch.empty_like(img), hyper=torch.empty(4, dtype=torch.float32, device=img.device),
+                                    calls=torch.zeros(1, dtype=torch.int32, device=img.device), gts={})
+            self._graphs = {}
+        if nmax not in S['gts']:
+            S['gts'][nmax] = torch.zeros(b, nmax, 5, dtype=torch.float32, device=img.device)
+        S['gt'] = S['gts'][nmax]
+        S['img'].copy_(img, non_blocking=True)
+        S['gt'].zero_()
+        if gt.shape[1]:
+            S['gt'][:, :gt.shape[1]].copy_(gt)
+        d = self.ema_decay * (1 - math.exp(-(st.steps + 1) / self.ema_tau))      # torch_utils.py:342 with updates = steps + 1
+        S['hyper'].copy_(torch.tensor([self.lr, self.lr_bias, self.mom, d], dtype=torch.float32), non_blocking=True)
+        S['calls'].fill_(int(self.crit.epoch))
+        if nmax not in self._graphs:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=self._pool):
+                self._graph_body()
+            if self._pool is None:
+                self._pool = g.pool()
+            self._graphs[nmax] = (g, S['out5'])
+        g, out5 = self._graphs[nmax]
+        g.replay()
+        ops.PARAM_EPOCH[0] += 1                     # the replay moved the weights: packed-weight caches of any eager forward are stale
+        st.steps += 1
+        self.crit.epoch += 1
+        self.last_opt_step = self.ni
+        self.ni += 1
+        return out5[0].clone(), out5[1:4].clone()
+
     def step(self, batch, epoch=0):
         st = self.state
         self.warmup(epoch)
+        if self._graph_ok():
+            return self._graph_step(batch)
         first_micro = self.ni == self.last_opt_step + 1            # first backward after an optimizer step (zero_grad)
         feats = self.model._predict_once(self.preprocess_batch(batch))
         # loss * world_size so that the mean all-reduce yields the global sum (trainer.py:337-338)
