@@ -19,11 +19,28 @@
 // `dgrad`: pack the weights of the data-gradient convolution instead - rows = input channels of the original conv, K = (flipped tap,
 // output channel): dx = conv(dy, w'[ci][co][ky][kx] = w[co][ci][KS-1-ky][KS-1-kx]) for stride 1.  Cin / Cout are then those of the
 // dgrad conv (Cin = original cout, Cout = original cin).
+// The BN fold of fold_kernel runs inline (same expressions, same bits): one launch per convolution instead of two - in training every
+// convolution is re-packed after every optimizer step.  FoldArgs.g == nullptr: no BN (scale 1); bias_out == nullptr: the caller folds.
+struct FoldArgs { const float *cb, *g, *b, *mu, *var; float eps; int cout_real, cpad; float* bias_out; };
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cin, int Cout, int KS,
-                            int CP, int nchunks, int NTtot, T* __restrict__ out, int dgrad = 0) {
+                            int CP, int nchunks, int NTtot, T* __restrict__ out, int dgrad = 0, FoldArgs fa = FoldArgs{}) {
   constexpr int PE = Piece<T>::PE;
   long total = (long)nchunks * NTtot * 64 * PE;
+  if (fa.bias_out && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < fa.cpad; c += blockDim.x) {
+      float bo = 0.f;
+      if (c < fa.cout_real) {
+        if (fa.g) {
+          const float s = fa.g[c] / sqrtf(fa.eps + fa.var[c]);
+          bo = fa.b[c] - fa.g[c] * fa.mu[c] / sqrtf(fa.var[c] + fa.eps);
+          if (fa.cb) bo += s * fa.cb[c];
+        } else if (fa.cb) {
+          bo = fa.cb[c];
+        }
+      }
+      fa.bias_out[c] = bo;
+    }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int j = (int)(i % PE);
     long t = i / PE;
@@ -45,6 +62,7 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
       }
       else v = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
       if (scale) v *= scale[cout];
+      else if (fa.g) v *= fa.g[cout] / sqrtf(fa.eps + fa.var[cout]);
     }
     out[i] = (T)v;
   }
@@ -98,10 +116,11 @@ extern "C" int mgdt_conv_pack(const float* w, const float* cb, const float* g, c
   hipStream_t st = (hipStream_t)s;
   float* scale = (float*)((char*)packed + (size_t)nchunks * NTtot * 1024);
   int cpad = NTtot * 16;
-  fold_kernel<<<cdiv(cpad, 64), 64, 0, st>>>(cb, g, b, mu, var, eps, cout, cpad, scale, bias_out);
+  (void)scale;
   long total = (long)nchunks * NTtot * 64 * piece_elems(dtype);
   int grid = (int)std::min<long>((total + 255) / 256, 4096);
-  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, g ? scale : nullptr, cin, cout, k, CP, nchunks, NTtot, (T*)packed)));
+  const FoldArgs fa{cb, g, b, mu, var, eps, cout, cpad, bias_out};
+  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cin, cout, k, CP, nchunks, NTtot, (T*)packed, 0, fa)));
   MGDT_CHECK_LAUNCH("conv_pack");
   return MGDT_OK;
 }
@@ -116,10 +135,11 @@ extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, in
   hipStream_t st = (hipStream_t)s;
   float* scale = (float*)((char*)packed + (size_t)nchunks * NTtot * 1024);
   const int cpad = NTtot * 16;
-  fold_kernel<<<cdiv(cpad, 64), 64, 0, st>>>(nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cin, cpad, scale, bias_out);
+  (void)scale;
   long total = (long)nchunks * NTtot * 64 * piece_elems(dtype);
   int grid = (int)std::min<long>((total + 255) / 256, 4096);
-  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cout, cin, k, CP, nchunks, NTtot, (T*)packed, phase < 0 ? 1 : 2 + phase)));
+  const FoldArgs fa{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cin, cpad, bias_out};      // zero bias
+  MGDT_DISPATCH_DTYPE(dtype, (pack_kernel<T><<<grid, 256, 0, st>>>(w, nullptr, cout, cin, k, CP, nchunks, NTtot, (T*)packed, phase < 0 ? 1 : 2 + phase, fa)));
   MGDT_CHECK_LAUNCH("conv_pack_dgrad");
   return MGDT_OK;
 }

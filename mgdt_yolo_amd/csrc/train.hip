@@ -326,7 +326,8 @@ bool mgdt_wgrad_mfma_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_
 // the partial buffer stays <= max(16 splits, 16 MiB)
 static inline int wgrad_splits(int cin, int cout, int k) {
   const long nel = (long)cin * cout * k * k;
-  return (int)std::max<long>(WG_SPLITS, std::min<long>(256, (4L << 20) / std::max<long>(nel, 1)));
+  static const long cap = getenv("MGDT_WGRAD_SPLITS") ? atol(getenv("MGDT_WGRAD_SPLITS")) : 512;     // experiment knob
+  return (int)std::max<long>(WG_SPLITS, std::min<long>(cap, (4L << 20) / std::max<long>(nel, 1)));
 }
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view x, const mgdt_view x2, const mgdt_view dy, int KS, int stride,
