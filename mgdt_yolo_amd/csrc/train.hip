@@ -15,10 +15,10 @@ bool mgdt_wgrad_bf16_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_
 bool mgdt_v4_add(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, hipStream_t st);
 bool mgdt_v4_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, hipStream_t st);
 // vectorised versions for pixel-linear views (bn_fast.hip); each returns false when a view does not qualify
-bool mgdt_bnf_stats(const mgdt_view* y, double* partial, int dtype, hipStream_t st);
+int mgdt_bnf_stats(const mgdt_view* y, double* partial, int dtype, hipStream_t st);      // returns the number of pixel splits written (0: not handled)
 bool mgdt_bnf_fwd(const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const mgdt_view* r1,
                   const mgdt_view* r2, const mgdt_view* z, int dtype, hipStream_t st);
-bool mgdt_bnf_bwd_partial(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+int mgdt_bnf_bwd_partial(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                           double* partial, int dtype, hipStream_t st);
 bool mgdt_bnf_bwd_apply(const mgdt_view* gz, const mgdt_view* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                         const float* coef, const mgdt_view* dy, int dtype, hipStream_t st);
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const mgdt_view y
 // together), thread 0 of the channel adds the 16 sub-sums in order - a fixed association, so the result does not depend on scheduling.
 // (One thread per channel walking all 512 rows was a ~100 us dependent chain per BN layer.)
 #define FIN_CW 16
-__device__ __forceinline__ bool final_sum(const double* __restrict__ partial, int C, int& c, double& s0, double& s1) {
+__device__ __forceinline__ bool final_sum(const double* __restrict__ partial, int C, int nsplit, int& c, double& s0, double& s1) {
   __shared__ double red[2][16][FIN_CW];
   const int cl = threadIdx.x % FIN_CW, part = threadIdx.x / FIN_CW;
   c = blockIdx.x * FIN_CW + cl;
   double a0 = 0.0, a1 = 0.0;
   if (c < C) {
-    constexpr int ROWS = RED_SPLITS / 16;
+    const int ROWS = nsplit / 16;                          // nsplit: a multiple of 16
 #pragma unroll 8
     for (int k = 0; k < ROWS; ++k) {
       const double2 v = *(const double2*)(partial + ((long)(part * ROWS + k) * C + c) * 2);
@@ -115,11 +115,11 @@ __device__ __forceinline__ bool final_sum(const double* __restrict__ partial, in
   return true;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* partial, int C, double count, float eps, float momentum, float* mean, float* rstd,
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* partial, int C, int nsplit, double count, float eps, float momentum, float* mean, float* rstd,
                                       float* running_mean, float* running_var) {
   int c;
   double s, ss;
-  if (!final_sum(partial, C, c, s, ss)) return;
+  if (!final_sum(partial, C, nsplit, c, s, ss)) return;
   double m = s / count, var = ss / count - m * m;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
@@ -137,11 +137,13 @@ extern "C" int mgdt_bn_stats_fwd(const mgdt_view* y, float eps, float momentum, 
                                  float* running_var, void* ws, int dtype, mgdt_stream s) {
   if (!view_ok(y) || !mean || !rstd || !ws) MGDT_FAIL(MGDT_BAD_ARG, "bn_stats: null/empty argument");
   if (y->sc != 1) MGDT_FAIL(MGDT_BAD_SHAPE, "bn_stats: NHWC view required");
-  if (!mgdt_bnf_stats(y, (double*)ws, dtype, (hipStream_t)s)) {
+  int ns = mgdt_bnf_stats(y, (double*)ws, dtype, (hipStream_t)s);
+  if (!ns) {
     dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
     MGDT_DISPATCH_DTYPE(dtype, (bn_stats_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*y, (double*)ws)));
+    ns = RED_SPLITS;
   }
-  bn_stats_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
+  bn_stats_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, ns, (double)y->n * y->h * y->w, eps, momentum, mean, rstd,
                                                                      running_mean, running_var);
   MGDT_CHECK_LAUNCH("bn_stats_fwd");
   return MGDT_OK;
@@ -202,10 +204,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const mgdt_view gz,
 }
 
 // per-channel totals of the two BN-backward sums (+ the parameter gradients), once, instead of RED_SPLITS loads per element
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* partial, int C, double count, double* sums, float* coef, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* partial, int C, int nsplit, double count, double* sums, float* coef, float* dgamma, float* dbeta) {
   int c;
   double sg, sgx;
-  if (!final_sum(partial, C, c, sg, sgx)) return;
+  if (!final_sum(partial, C, nsplit, c, sg, sgx)) return;
   sums[2 * c] = sg; sums[2 * c + 1] = sgx;
   coef[2 * c] = (float)(sg / count); coef[2 * c + 1] = (float)(sgx / count);     // what the apply pass subtracts, divided once
   if (dbeta) dbeta[c] = (float)sg;
@@ -247,10 +249,13 @@ extern "C" int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const fl
   dim3 grid(cdiv(y->c, red_cw(y->c)), RED_SPLITS);
   long total = (long)y->n * y->h * y->w * y->c;
   double* sums = (double*)ws + (size_t)RED_SPLITS * y->c * 2;
-  if (!mgdt_bnf_bwd_partial(gz, y, mean, rstd, gamma, beta, act, (double*)ws, dtype, (hipStream_t)s))
+  int ns = mgdt_bnf_bwd_partial(gz, y, mean, rstd, gamma, beta, act, (double*)ws, dtype, (hipStream_t)s);
+  if (!ns) {
     MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_partial_kernel<T><<<grid, 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, (double*)ws)));
+    ns = RED_SPLITS;
+  }
   float* coef = (float*)(sums + (size_t)y->c * 2);
-  bn_bwd_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, (double)y->n * y->h * y->w, sums, coef, dgamma, dbeta);
+  bn_bwd_final_kernel<<<cdiv(y->c, FIN_CW), 256, 0, (hipStream_t)s>>>((const double*)ws, y->c, ns, (double)y->n * y->h * y->w, sums, coef, dgamma, dbeta);
   if (!mgdt_bnf_bwd_apply(gz, y, mean, rstd, gamma, beta, act, coef, dy, dtype, (hipStream_t)s))
     MGDT_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*gz, *y, mean, rstd, gamma, beta, act, sums,
                                                                                                  (double)y->n * y->h * y->w, *dy)));
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const mgdt_view 
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(const double* partial, int C, float* db, int accumulate) {
   int c;
   double s, unused;
-  if (!final_sum(partial, C, c, s, unused)) return;
+  if (!final_sum(partial, C, RED_SPLITS, c, s, unused)) return;
   db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
 

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void dwconv7_dgrad_vec_kernel(const mgdt_view 
 
 // depthwise weight gradient: block = (ky, split); thread = (channel quad, pixel lane) holds the 7 kx taps x 4 channels of its row ky in
 // registers (du read once per 7 taps), bias sum rides with ky == 0.  part[split][50][C].
-#define DWV_SPLITS 160
+#define DWV_SPLITS 320
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_vec_kernel(const mgdt_view x, const mgdt_view du, float* part) {
   const int C = du.c, Q = C >> 2, ky = blockIdx.x, split = blockIdx.y;

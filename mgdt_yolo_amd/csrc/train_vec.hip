@@ -214,13 +214,26 @@ __global__ __launch_bounds__(256) void v4_nc_reduce_partial_kernel(const mgdt_vi
   for (int q0 = 0; q0 < Q; q0 += QB) {
     const int q = q0 + ql;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (q < Q && pl < PL)
-      for (int p = p0 + pl; p < p1; p += PL) {
+    if (q < Q && pl < PL) {
+      int p = p0 + pl;
+      for (; p + 3 * PL < p1; p += 4 * PL) {                // four pixels in flight: the loop is a chain of dependent-latency round trips otherwise
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p + u * PL, yy = pp / a.w, xx = pp - yy * a.w;
+          v[u] = load4<T>(P4(const T, a, (long)n, yy, xx, 4 * q));
+          if (b.p) v[u] = v[u] * load4<T>(P4(const T, b, (long)n, yy, xx, 4 * q));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+      }
+      for (; p < p1; p += PL) {
         const int yy = p / a.w, xx = p - yy * a.w;
         f32x4 v = load4<T>(P4(const T, a, (long)n, yy, xx, 4 * q));
         if (b.p) v = v * load4<T>(P4(const T, b, (long)n, yy, xx, 4 * q));
         acc += v;
       }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = acc[j];
@@ -251,13 +264,15 @@ __global__ __launch_bounds__(256) void v4_maxpool5_bwd_kernel(const mgdt_view x,
   extern __shared__ float lds[];
   const int H = x.h, W = x.w, HW = H * W, n = blockIdx.x, c0 = blockIdx.y * CB;
   float* xs = lds;                                      // [HW][CB]
-  unsigned short* am = (unsigned short*)(lds + (size_t)HW * CB);   // [HW][CB] argmax pixel index
+  float* gs = lds + (size_t)HW * CB;                    // [HW][CB] gy
+  unsigned short* am = (unsigned short*)(gs + (size_t)HW * CB);   // [HW][CB] argmax pixel index
   const int QB = CB >> 2;
   for (int i = threadIdx.x; i < HW * QB; i += 256) {
     const int p = i / QB, q = i - p * QB;
     const int yy = p / W, xx = p - yy * W;
-    const f32x4 v = (c0 + 4 * q < x.c) ? load4<T>(P4(const T, x, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    *(f32x4*)(xs + (size_t)p * CB + 4 * q) = v;
+    const bool in = c0 + 4 * q < x.c;
+    *(f32x4*)(xs + (size_t)p * CB + 4 * q) = in ? load4<T>(P4(const T, x, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(gs + (size_t)p * CB + 4 * q) = in ? load4<T>(P4(const T, gy, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   for (int i = threadIdx.x; i < HW * CB; i += 256) {
@@ -287,20 +302,20 @@ __global__ __launch_bounds__(256) void v4_maxpool5_bwd_kernel(const mgdt_view x,
       if ((unsigned)oy >= (unsigned)H) continue;
       for (int ox = w - 2; ox <= w + 2; ++ox) {
         if ((unsigned)ox >= (unsigned)W) continue;
-        if (am[(size_t)(oy * W + ox) * CB + c] == p) acc += (float)((const T*)gy.p)[(long)n * gy.sn + oy * gy.sh + ox * gy.sw + c0 + c];
+        if (am[(size_t)(oy * W + ox) * CB + c] == p) acc += gs[(size_t)(oy * W + ox) * CB + c];
       }
     }
     gx_f32[((long)n * HW + p) * x.c + c0 + c] = acc;
   }
 }
 bool mgdt_v4_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, hipStream_t st) {
-  if (!v4_ok(x, dtype)) return false;
+  if (!v4_ok(x, dtype) || !v4_ok(gy, dtype)) return false;
   const long HW = (long)x->h * x->w;
   if (HW > 65535) return false;
-  int CB = 32;
-  while (CB > 4 && HW * CB * 6 > 64 * 1024) CB >>= 1;       // xs (4 B) + argmax (2 B) per element within the default 64 KB
-  if (HW * CB * 6 > 64 * 1024) return false;
-  const size_t lds = (size_t)HW * CB * 6;
+  int CB = 16;
+  while (CB > 4 && HW * CB * 10 > 64 * 1024) CB >>= 1;      // x (4 B) + gy (4 B) + argmax (2 B) per element within the default 64 KB
+  if (HW * CB * 10 > 64 * 1024) return false;
+  const size_t lds = (size_t)HW * CB * 10;
   MGDT_DISPATCH_DTYPE(dtype, (v4_maxpool5_bwd_kernel<T><<<dim3(x->n, (x->c + CB - 1) / CB), 256, lds, st>>>(*x, *gy, gx_f32, CB)));
   return true;
 }
