@@ -329,6 +329,36 @@ size_t mgdt_ap_workspace_bytes(int n_det, int n_cls);
 int mgdt_ap_per_class(const void* tp, const float* conf, const int32_t* seg, const int32_t* nlab, int n_det, int n_cls, int T, const double* x101,
                       const double* px, double eps, void* ws, double* ap, double* pcur, double* rcur, mgdt_stream s);
 
+/* ---- TOODHead training (reference nn/modules/head.py:466-572 under autograd; mmcv ModulatedDeformConv2d backward) -----------------------
+ * GroupNorm(16)+act backward of Conv_GN / DyDCNv2.norm (head.py:67-81, block.py:401-432), composed with mgdt_nc_reduce:
+ *   gn_affine:          Sy = sum_hw y, Syy = sum_hw y*y  ->  mean / rstd per (image, group), A = gamma*rstd, B = beta - mean*rstd*gamma  (u = y*A + B)
+ *   nc_affine_act_bwd:  gu = g * act'(y*A + B)        (A = B = NULL: u = y, i.e. with act = ReLU and y the layer output the ReLU mask)
+ *   gn_bwd_coef:        S1 = sum_hw gu, S2 = sum_hw gu*y  ->  P, Q, R with dy = gu*P + y*Q + R, and dgamma / dbeta (written or accumulated: the head is
+ *                       shared by all levels); ws: mgdt_gn_bwd_workspace_bytes
+ *   nc_axpby:           out = a*sa[n][c] (+ b*sb[n][c]) (+ shift[n][c])     (sa NULL: 1)
+ * pixel_gate_bwd: adjoint of mgdt_pixel_gate_fwd (cls_feat * sigmoid(prob logit), head.py:530-537): gx = g*s, glogit = s(1-s) * sum_c g*x.
+ * tood_layer_attn_bwd: adjoint of mgdt_tood_layer_attn_fwd (TaskDecomposition.forward head.py:107-116): dscale [n][c] -> dsums [n][c] (gradient
+ *   w.r.t. sum_hw feat) and dW1 (hid*c), db1 (hid), dW2 (stacked*hid), db2 (stacked), written or accumulated.
+ * dcn_im2col: col[n,y,x,c*9 + tap] = sigmoid(mask logit) * bilinear(x at p + offset) (mmcv modulated_deformable_im2col): the DCN output is the
+ *   1x1 convolution of col with weight.view(cout, cin*9), so its weight / column gradients are mgdt_conv_wgrad / dgrad.
+ * dcn_col2im_bwd: column gradient -> gx_f32 (dense fp32 NHWC, ZERO on entry; float atomics, the order-dependent scatter of mmcv's col2im) and
+ *   gom (offset gradients 0..17, mask-LOGIT gradients 18..26, further channels zeroed) (mmcv modulated_deformable_col2im / col2im_coord). */
+int mgdt_gn_affine(const float* Sy, const float* Syy, int n, int c, int hw, const float* gamma, const float* beta, int groups, float eps,
+                   float* mean_ng, float* rstd_ng, float* A, float* B, mgdt_stream s);
+int mgdt_nc_affine_act_bwd(const mgdt_view* g, const mgdt_view* y, const float* A, const float* B, int act, const mgdt_view* gu, int dtype, mgdt_stream s);
+size_t mgdt_gn_bwd_workspace_bytes(int n, int c);
+int mgdt_gn_bwd_coef(const float* S1, const float* S2, const float* mean_ng, const float* rstd_ng, const float* gamma, int n, int c, int hw, int groups,
+                     float* P, float* Q, float* R, float* dgamma, float* dbeta, int accumulate, void* ws, mgdt_stream s);
+int mgdt_nc_axpby(const mgdt_view* a, const float* sa, const mgdt_view* b, const float* sb, const float* shift, const mgdt_view* out, int dtype,
+                  mgdt_stream s);
+int mgdt_pixel_gate_bwd(const mgdt_view* g, const mgdt_view* x, const mgdt_view* logit, const mgdt_view* gx, const mgdt_view* glogit, int dtype, mgdt_stream s);
+size_t mgdt_tood_layer_attn_bwd_workspace_bytes(int n, int c, int hid, int stacked);
+int mgdt_tood_layer_attn_bwd(const float* sums, const float* dscale, int n, int c, int hw, const float* w1, const float* b1, const float* w2,
+                             const float* b2, int hid, int stacked, float* dsums, float* dw1, float* db1, float* dw2, float* db2, int accumulate,
+                             void* ws, mgdt_stream s);
+int mgdt_dcn_im2col(const mgdt_view* x, const mgdt_view* om, const mgdt_view* col, int dtype, mgdt_stream s);
+int mgdt_dcn_col2im_bwd(const mgdt_view* gcol, const mgdt_view* x, const mgdt_view* om, float* gx_f32, const mgdt_view* gom, int dtype, mgdt_stream s);
+
 #ifdef __cplusplus
 }
 #endif

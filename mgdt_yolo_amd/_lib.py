@@ -65,6 +65,16 @@ PROTOTYPES = {
     'mgdt_dcnv2_fwd': (_i, [VP, VP, _vp, _vp, VP, _i, _vp]),
     'mgdt_dcnv2_mfma_fwd': (_i, [VP, VP, _vp, VP, _i, _vp]),
     'mgdt_pixel_gate_fwd': (_i, [VP, VP, VP, _i, _vp]),
+    'mgdt_gn_affine': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    'mgdt_nc_affine_act_bwd': (_i, [VP, VP, _vp, _vp, _i, VP, _i, _vp]),
+    'mgdt_gn_bwd_workspace_bytes': (_sz, [_i, _i]),
+    'mgdt_gn_bwd_coef': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'mgdt_nc_axpby': (_i, [VP, _vp, VP, _vp, _vp, VP, _i, _vp]),
+    'mgdt_pixel_gate_bwd': (_i, [VP, VP, VP, VP, VP, _i, _vp]),
+    'mgdt_tood_layer_attn_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'mgdt_tood_layer_attn_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'mgdt_dcn_im2col': (_i, [VP, VP, VP, _i, _vp]),
+    'mgdt_dcn_col2im_bwd': (_i, [VP, VP, VP, _vp, VP, _i, _vp]),
     'mgdt_val_match_fwd': (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'mgdt_grn_stats_fwd': (_i, [VP, _vp, _vp, _vp, _i, _vp]),
     'mgdt_inject_fwd': (_i, [VP, VP, VP, VP, _i, _vp]),

@@ -33,11 +33,11 @@ class _HeadConv(HipModule):
         return ops.conv2d(x, pk, 1, ops.ACT_NONE, out=out)
 
     @staticmethod
-    def backward(conv, x, g):
-        """Plain conv + bias: fills conv.weight.grad / conv.bias.grad, returns dx."""
+    def backward(conv, x, g, accumulate=False):
+        """Plain conv + bias: fills (or adds to: a head shared by several levels) conv.weight.grad / conv.bias.grad, returns dx."""
         ops.grad_buf(conv.weight)
         ops.grad_buf(conv.bias)
-        ops.conv_wgrad(x, g, 1, 1, conv.weight.grad, dbias=conv.bias.grad)
+        ops.conv_wgrad(x, g, 1, 1, conv.weight.grad, dbias=conv.bias.grad, accumulate=accumulate)
         dx = ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.dtype, x.device)
         return ops.conv_dgrad(g, conv.weight, 1, 1, dx)
 
@@ -179,14 +179,27 @@ class Conv_GN(HipModule):
 
     def forward(self, x, out=None):
         from .conv import act_code
-        if self.training:
-            raise NotImplementedError('TOODHead training kernels are not built yet')
         dt = self.out_dtype(x)
         k, st = self.conv.kernel_size[0], self.conv.stride[0]
         mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, st, 1, dt)
         pk = self._cached(('raw', dt, not mfma), [self.conv.weight], lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma))
         y = ops.conv2d(x, pk, st, ops.ACT_NONE)
-        return ops.groupnorm(y, self.gn.weight.detach().float(), self.gn.bias.detach().float(), self.gn.num_groups, self.gn.eps, act_code(self.act), out=out)
+        z = ops.groupnorm(y, self.gn.weight.detach().float(), self.gn.bias.detach().float(), self.gn.num_groups, self.gn.eps, act_code(self.act), out=out)
+        if self.training:
+            self._save_ctx((x, y))
+        return z
+
+    def backward(self, g, accumulate=False):
+        """d loss / d x; parameter gradients written, or added when `accumulate` (the head is shared by the levels)."""
+        from .conv import act_code
+        x, y = self._ctx.pop()
+        for p in (self.conv.weight, self.gn.weight, self.gn.bias):
+            ops.grad_buf(p)
+        dy = ops.gn_act_bwd(g, y, self.gn.weight.detach().float(), self.gn.bias.detach().float(), self.gn.num_groups, self.gn.eps, act_code(self.act),
+                            self.gn.weight.grad, self.gn.bias.grad, accumulate)
+        k = self.conv.kernel_size[0]
+        ops.conv_wgrad(x, dy, k, 1, self.conv.weight.grad, accumulate=accumulate)
+        return ops.conv_dgrad(dy, self.conv.weight, k, 1, ops.like(x))
 
 
 class _ConvModuleBias(nn.Module):
@@ -226,7 +239,25 @@ class TaskDecomposition(HipModule):
         dt = self.out_dtype(feat)
         # as written in the reference the bmm path uses only `.conv.weight`: reduction_conv's bias parameter is never added (head.py:117-127)
         pk = self._cached(('red', dt), [rc.weight], lambda: ops.PackedConv(rc.weight, None, None, 1, dt))
-        return ops.conv2d(feat, pk, 1, ops.ACT_RELU, in_scale=scale)
+        out = ops.conv2d(feat, pk, 1, ops.ACT_RELU, in_scale=scale)
+        if self.training:
+            self._save_ctx((feat, scale, sums if sums is not None else ops.nc_reduce(feat), out, la))
+        return out
+
+    def backward(self, g, accumulate=False):
+        """-> (t, scale, dsums): d loss / d feat = t * scale[n, c] + dsums[n, c] (the GAP branch, already divided by H*W); the caller sums the
+        two decompositions in one pass."""
+        feat, scale, sums, out, la = self._ctx.pop()
+        rc = self.reduction_conv.conv
+        for p in (rc.weight, self.la_conv1.weight, self.la_conv1.bias, self.la_conv2.weight, self.la_conv2.bias):
+            ops.grad_buf(p)
+        gr = ops.relu_mask(g, out)
+        ops.conv_wgrad(ops.channel_affine(feat, scale, None), gr, 1, 1, rc.weight.grad, accumulate=accumulate)      # d W = sum (feat * scale) x g
+        t = ops.conv_dgrad(gr, rc.weight, 1, 1, ops.like(feat))
+        dscale = ops.nc_reduce(t, feat)
+        dsums = ops.tood_layer_attn_bwd(sums, dscale, feat.shape[2] * feat.shape[3], la[0], la[1], la[2], la[3], self.stacked_convs,
+                                        self.la_conv1.weight.grad, self.la_conv1.bias.grad, self.la_conv2.weight.grad, self.la_conv2.bias.grad, accumulate)
+        return t, scale, dsums
 
 
 class _DCNParams(nn.Module):
@@ -254,6 +285,17 @@ class DyDCNv2(HipModule):
     def forward(self, x, offset_mask, act=ops.ACT_NONE):
         """offset_mask: (B, >=27, H, W) = 18 offsets + 9 mask LOGITS (the sigmoid of head.py:525 runs inside the kernel)."""
         cw = self.conv.weight
+        if self.training:
+            # training: the sampled-and-modulated columns are materialised once; the DCN is then the 1x1 conv of col with weight.view(cout, cin*9)
+            if self.conv.bias is not None or not self.with_norm:
+                raise NotImplementedError('DyDCNv2 training: only the normalised, bias-free form the head builds')
+            dt = x.dtype
+            col = ops.dcn_im2col(x, offset_mask)
+            pk1 = self._cached(('col1x1', dt), [cw], lambda: ops.PackedConv(cw.detach().reshape(cw.shape[0], cw.shape[1] * 9, 1, 1), None, None, 1, dt))
+            d = ops.conv2d(col, pk1, 1, ops.ACT_NONE)
+            z = ops.groupnorm(d, self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.num_groups, self.norm.eps, act)
+            self._save_ctx((x, offset_mask, col, d, act))
+            return z
         wg = self._cached('gemm', [cw], lambda: cw.detach().float().permute(2, 3, 1, 0).reshape(9 * cw.shape[1], cw.shape[0]).contiguous())
         b = None if self.conv.bias is None else self.conv.bias.detach().float()
         if (b is None and x.dtype == torch.bfloat16 and offset_mask.dtype == x.dtype and cw.shape[1] % 8 == 0 and cw.shape[0] % 16 == 0 and cw.shape[0] <= 64
@@ -265,6 +307,20 @@ class DyDCNv2(HipModule):
         if not self.with_norm:
             return y
         return ops.groupnorm(y, self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.num_groups, self.norm.eps, act, out=y)
+
+
+    def backward(self, g, accumulate=False):
+        """-> (d loss / d x, d loss / d offset_mask map)."""
+        x, om, col, d, act = self._ctx.pop()
+        cw = self.conv.weight
+        for p in (cw, self.norm.weight, self.norm.bias):
+            ops.grad_buf(p)
+        gd = ops.gn_act_bwd(g, d, self.norm.weight.detach().float(), self.norm.bias.detach().float(), self.norm.num_groups, self.norm.eps, act,
+                            self.norm.weight.grad, self.norm.bias.grad, accumulate)
+        w1 = cw.detach().reshape(cw.shape[0], cw.shape[1] * 9, 1, 1)
+        ops.conv_wgrad(col, gd, 1, 1, cw.grad.view(cw.shape[0], cw.shape[1] * 9, 1, 1), accumulate=accumulate)
+        gcol = ops.conv_dgrad(gd, w1, 1, 1, ops.like(col))
+        return ops.dcn_col2im_bwd(gcol, x, om)
 
 
 class TOODHead(Detect):
@@ -309,8 +365,6 @@ class TOODHead(Detect):
         return ops.conv2d(x, pk, 1, act)
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError('TOODHead training kernels are not built yet (inference only this round)')
         shape = x[0].shape
         r4 = 4 * self.reg_max
         for i in range(self.nl):
@@ -326,11 +380,17 @@ class TOODHead(Detect):
             reg_feat = self.reg_decomp(feat, sums)
             om = self._bias_conv(self.spatial_conv_offset, feat, ops.ACT_NONE, dt, pad_to=28)     # 18 offsets | 9 mask logits | pad
             reg_feat = self.DyDCNV2(reg_feat, om, act=ops.ACT_RELU)      # F.relu(reg_feat) of head.py:537 folded into the GroupNorm pass
-            prob = self._bias_conv(self.cls_prob_conv2, self._bias_conv(self.cls_prob_conv1, feat, ops.ACT_RELU, dt), ops.ACT_NONE, dt)
+            p1 = self._bias_conv(self.cls_prob_conv1, feat, ops.ACT_RELU, dt)
+            prob = self._bias_conv(self.cls_prob_conv2, p1, ops.ACT_NONE, dt)
             out = ops.new_act(b, self.no, h, w, dt, xi.device)
+            gated = ops.pixel_gate(cls_feat, prob)
             _HeadConv.run(self, self.cv2, reg_feat, out[:, :r4])
-            _HeadConv.run(self, self.cv3, ops.pixel_gate(cls_feat, prob), out[:, r4:])
+            _HeadConv.run(self, self.cv3, gated, out[:, r4:])
+            if self.training:
+                self._save_ctx(dict(feat=feat, half=half, om=om, reg_feat=reg_feat, cls_feat=cls_feat, p1=p1, prob=prob, gated=gated))
             x[i] = out
+        if self.training:
+            return x
         strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])
         if self.dynamic or self.shape != shape:
             from ...yolo.utils.tal import make_anchors
@@ -344,8 +404,59 @@ class TOODHead(Detect):
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
 
+    def _bias_conv_bwd(self, conv, x, g, pad_to=None, accumulate=False):
+        """Backward of _bias_conv (without its activation): parameter gradients (+=), returns dx."""
+        ops.grad_buf(conv.weight)
+        ops.grad_buf(conv.bias)
+        k = conv.kernel_size[0]
+        w = conv.weight
+        if pad_to and pad_to > w.shape[0]:          # g carries the zero padding channels of the forward
+            wp = self._cached(('wpad', id(conv), pad_to), [w], lambda: torch.cat([w.detach().float(), w.new_zeros(pad_to - w.shape[0], *w.shape[1:])]).contiguous())
+            dwp = torch.empty_like(wp)
+            dbp = torch.empty(pad_to, dtype=torch.float32, device=w.device)
+            ops.conv_wgrad(x, g, k, 1, dwp, dbias=dbp)
+            (conv.weight.grad.add_ if accumulate else conv.weight.grad.copy_)(dwp[:w.shape[0]])
+            (conv.bias.grad.add_ if accumulate else conv.bias.grad.copy_)(dbp[:w.shape[0]])
+            return ops.conv_dgrad(g, wp, k, 1, ops.like(x))
+        ops.conv_wgrad(x, g, k, 1, conv.weight.grad, dbias=conv.bias.grad, accumulate=accumulate)
+        return ops.conv_dgrad(g, w, k, 1, ops.like(x))
+
     def backward(self, grads):
-        raise NotImplementedError('TOODHead training kernels are not built yet')
+        """grads: d loss / d raw maps, one per level.  The head is shared: the levels are walked last to first (every sub-module's saved-state
+        stack is LIFO) and parameter gradients are written by the first level processed, accumulated by the others.  Parameters the reference's
+        forward never touches (`scale.*`, `reduction_conv.conv.bias`) get zero gradients."""
+        r4 = 4 * self.reg_max
+        out = [None] * self.nl
+        for p in [m.scale for m in self.scale] + [self.cls_decomp.reduction_conv.conv.bias, self.reg_decomp.reduction_conv.conv.bias]:
+            ops.grad_buf(p).zero_()
+        for step, i in enumerate(reversed(range(self.nl))):
+            acc = step > 0
+            c = self._ctx.pop()
+            g = grads[i]
+            feat, half = c['feat'], c['half']
+            hw = feat.shape[2] * feat.shape[3]
+            # box branch: cv2 <- reg_feat = relu(GN(DCN(reg_feat0, om)))   (ReLU folded into the GroupNorm backward)
+            g_reg = _HeadConv.backward(self.cv2, c['reg_feat'], g[:, :r4], accumulate=acc)
+            g_reg0, g_om = self.DyDCNV2.backward(g_reg, accumulate=acc)
+            # class branch: cv3 <- cls_feat * sigmoid(prob)
+            g_gated = _HeadConv.backward(self.cv3, c['gated'], g[:, r4:], accumulate=acc)
+            # cls_prob_conv2 has ONE output channel: its gradient map is kept as channel 0 of a zero 4-channel map so that the weight-gradient
+            # kernel sees 4-aligned channels (pad_to=4 below drops the padding rows again)
+            gp4 = ops.new_act(g.shape[0], 4, g.shape[2], g.shape[3], g.dtype, g.device).zero_()
+            g_cls, _ = ops.pixel_gate_bwd(g_gated, c['cls_feat'], c['prob'], glogit=gp4[:, :1])
+            g_p1 = ops.relu_mask(self._bias_conv_bwd(self.cls_prob_conv2, c['p1'], gp4, pad_to=4, accumulate=acc), c['p1'])
+            gf = self._bias_conv_bwd(self.cls_prob_conv1, feat, g_p1, accumulate=acc)                       # d feat, accumulated below
+            gf = ops.add(gf, self._bias_conv_bwd(self.spatial_conv_offset, feat, g_om, pad_to=28, accumulate=acc), out=gf)
+            # the two task decompositions (processed in reverse order of the forward: reg, then cls)
+            t_r, s_r, ds_r = self.reg_decomp.backward(g_reg0, accumulate=acc)
+            t_c, s_c, ds_c = self.cls_decomp.backward(g_cls, accumulate=acc)
+            gd = ops.nc_axpby(t_c, s_c, t_r, s_r, ops.ew_add_nc(ds_c, ds_r))                                 # t_c*s_c + t_r*s_r + (dsums_c + dsums_r)[n, c]
+            gf = ops.add(gf, gd, out=gf)
+            # feat = [f0 | f1]: f1 = share_conv[1](f0), f0 = share_conv[0](x)
+            g_f0 = self.share_conv[1].backward(gf[:, half:], accumulate=acc)
+            g_f0 = ops.add(g_f0, gf[:, :half], out=g_f0)
+            out[i] = self.share_conv[0].backward(g_f0, accumulate=acc)
+        return out
 
     def bias_init(self):
         """reference head.py:562-568 (single shared head: the class prior uses stride 16)."""

@@ -470,6 +470,93 @@ def pixel_gate(x, gate, out=None):
     return out
 
 
+# ---- TOODHead training (tood_train.hip) ----
+def gn_affine(y, gamma, beta, groups, eps):
+    """GroupNorm of the conv output y as the per-(image, channel) affine u = y*A + B; returns (A, B, mean, rstd) fp32."""
+    b, c, h, w = y.shape
+    sy, syy = nc_reduce(y), nc_reduce(y, y)
+    dev = y.device
+    A, B = torch.empty(b, c, dtype=torch.float32, device=dev), torch.empty(b, c, dtype=torch.float32, device=dev)
+    mean, rstd = torch.empty(b, groups, dtype=torch.float32, device=dev), torch.empty(b, groups, dtype=torch.float32, device=dev)
+    _launch('gn_affine', 'mgdt_gn_affine', ptr(sy), ptr(syy), b, c, h * w, ptr(gamma), ptr(beta), groups, float(eps), ptr(mean), ptr(rstd), ptr(A), ptr(B), stream())
+    return A, B, mean, rstd
+
+
+def nc_affine_act_bwd(g, y, A, B, act):
+    gu = like(y)
+    _same(g, y)
+    _launch('nc_affine_act_bwd', 'mgdt_nc_affine_act_bwd', vp(g), vp(y), ptr(A), ptr(B), act, vp(gu), dtype_code(y.dtype), stream())
+    return gu
+
+
+def relu_mask(g, out_act):
+    """g * (out_act > 0): backward of a fused ReLU from its OUTPUT."""
+    return nc_affine_act_bwd(g, out_act, None, None, ACT_RELU)
+
+
+def nc_axpby(a, sa, b=None, sb=None, shift=None, out=None):
+    out = like(a) if out is None else out
+    _same(a, b, out)
+    _launch('nc_axpby', 'mgdt_nc_axpby', vp(a), ptr(sa), vp(b), ptr(sb), ptr(shift), vp(out), dtype_code(a.dtype), stream())
+    return out
+
+
+def gn_act_bwd(g, y, gamma, beta, groups, eps, act, dgamma, dbeta, accumulate=False):
+    """Backward of z = act(GroupNorm(y)): returns dy; dgamma / dbeta written or accumulated."""
+    b, c, h, w = y.shape
+    A, B, mean, rstd = gn_affine(y, gamma, beta, groups, eps)
+    gu = nc_affine_act_bwd(g, y, A, B, act)
+    s1, s2 = nc_reduce(gu), nc_reduce(gu, y)
+    P, Q, R = (torch.empty(b, c, dtype=torch.float32, device=y.device) for _ in range(3))
+    ws = torch.empty(L.lib().mgdt_gn_bwd_workspace_bytes(b, c), dtype=torch.uint8, device=y.device)
+    _launch('gn_bwd_coef', 'mgdt_gn_bwd_coef', ptr(s1), ptr(s2), ptr(mean), ptr(rstd), ptr(gamma), b, c, h * w, groups, ptr(P), ptr(Q), ptr(R), ptr(dgamma), ptr(dbeta),
+            int(accumulate), ptr(ws), stream())
+    return nc_axpby(gu, P, y, Q, R, out=gu)
+
+
+def pixel_gate_bwd(g, x, logit, glogit=None):
+    """-> (gx, glogit); `glogit` may be a one-channel view of a wider zero-filled buffer (the padded gradient of a 1-output conv)."""
+    gx = like(x)
+    gl = like(logit) if glogit is None else glogit
+    _same(g, x, logit, gl)
+    _launch('pixel_gate_bwd', 'mgdt_pixel_gate_bwd', vp(g), vp(x), vp(logit), vp(gx), vp(gl), dtype_code(x.dtype), stream())
+    return gx, gl
+
+
+def tood_layer_attn_bwd(sums, dscale, hw, w1, b1, w2, b2, stacked, dw1, db1, dw2, db2, accumulate=False):
+    n, c = sums.shape
+    hid = w1.shape[0]
+    dsums = torch.empty_like(sums)
+    ws = torch.empty(L.lib().mgdt_tood_layer_attn_bwd_workspace_bytes(n, c, hid, stacked), dtype=torch.uint8, device=sums.device)
+    _launch('tood_layer_attn_bwd', 'mgdt_tood_layer_attn_bwd', ptr(sums), ptr(dscale), n, c, hw, ptr(w1), ptr(b1), ptr(w2), ptr(b2), hid, stacked, ptr(dsums),
+            ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), int(accumulate), ptr(ws), stream())
+    return dsums
+
+
+def dcn_im2col(x, om):
+    b, c, h, w = x.shape
+    col = new_act(b, 9 * c, h, w, x.dtype, x.device)
+    _same(x, om)
+    _launch('dcn_im2col', 'mgdt_dcn_im2col', vp(x), vp(om), vp(col), dtype_code(x.dtype), stream())
+    return col
+
+
+def dcn_col2im_bwd(gcol, x, om):
+    """-> (gx in x's dtype, gom like om)."""
+    b, c, h, w = x.shape
+    gx32 = torch.zeros(b, h, w, c, dtype=torch.float32, device=x.device)
+    gom = like(om)
+    _same(gcol, x, om)
+    _launch('dcn_col2im_bwd', 'mgdt_dcn_col2im_bwd', vp(gcol), vp(x), vp(om), ptr(gx32), vp(gom), dtype_code(x.dtype), stream())
+    gx = gx32.permute(0, 3, 1, 2)                          # (B,C,H,W) view of the NHWC buffer = channels_last
+    return (gx if x.dtype == torch.float32 else copy(gx, like(x))), gom
+
+
+def ew_add_nc(a, b):
+    """Sum of two small fp32 [n, c] coefficient arrays (torch element-wise on a few hundred values)."""
+    return a + b
+
+
 def inject(local, ga, gf, out=None):
     out = like(local) if out is None else out
     _same(local, ga, gf, out)
