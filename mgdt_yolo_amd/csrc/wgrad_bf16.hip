@@ -235,21 +235,24 @@ static void wb_launch(const WbArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // Called by mgdt_conv_wgrad (train.hip) for bf16 NHWC inputs; partial: fp32 [nsplit][cout][cin][k*k].  false -> the caller keeps the fp32 MFMA kernel.
 bool mgdt_wgrad_bf16_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* partial, int nsplit, hipStream_t st) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (k == 1 && stride != 1) || x->sc != 1 || dy->sc != 1) return false;
-  if (x->c % 8 || dy->c % 8) return false;
+  // input channels in multiples of 4: an 8-channel item of a 4-channel-granular tensor also carries the next pixel's first channels; they only
+  // reach accumulators of input channels >= Cin, which the epilogue never writes (each (cout, cin) sum is independent)
+  if (x->c % 4 || dy->c % 8) return false;
   WbArgs a;
   memset(&a, 0, sizeof(a));
   bool fits = true;
-  auto bind = [&](const mgdt_view* v, const char** p, int* sn, int* sh, int* sw, uint32_t* bytes) {
+  auto bind = [&](const mgdt_view* v, const char** p, int* sn, int* sh, int* sw, uint32_t* bytes, int al) {
     const long ext = ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * 2;
-    if (ext >= 0x7fffffffL || (uintptr_t)v->p % 16 || v->sn % 8 || v->sh % 8 || v->sw % 8) { fits = false; return; }
+    if (ext >= 0x7fffffffL || (uintptr_t)v->p % (2 * al) || v->sn % al || v->sh % al || v->sw % al) { fits = false; return; }
     *p = (const char*)v->p; *sn = (int)(v->sn * 2); *sh = (int)(v->sh * 2); *sw = (int)(v->sw * 2); *bytes = (uint32_t)ext;
   };
-  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes);
+  const int xal = x->c % 8 ? 4 : 8;
+  bind(x, &a.x, &a.xsn, &a.xsh, &a.xsw, &a.x_bytes, xal);
   if (x2 && x2->p) {
     if (x2->sc != 1) return false;
-    bind(x2, &a.x2, &a.x2sn, &a.x2sh, &a.x2sw, &a.x2_bytes);
+    bind(x2, &a.x2, &a.x2sn, &a.x2sh, &a.x2sw, &a.x2_bytes, xal);
   }
-  bind(dy, &a.dy, &a.dsn, &a.dsh, &a.dsw, &a.dy_bytes);
+  bind(dy, &a.dy, &a.dsn, &a.dsh, &a.dsw, &a.dy_bytes, 8);
   if (!fits) return false;
   a.partial = partial;
   a.H = x->h; a.W = x->w; a.Cin = x->c; a.Ho = dy->h; a.Wo = dy->w; a.Cout = dy->c; a.KS = k; a.stride = stride; a.pad = k / 2; a.nsplit = nsplit;

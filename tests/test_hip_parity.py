@@ -1209,6 +1209,7 @@ WGRAD_BF16_CASES = [  # (B, cin, cout, H, W, k, stride, x2, sliced views)
     (2, 8, 8, 16, 16, 1, 1, False, True), (2, 48, 24, 10, 10, 1, 1, False, False), (1, 128, 64, 8, 8, 3, 1, True, True),
     (4, 16, 16, 12, 12, 3, 1, True, True), (4, 32, 16, 12, 12, 3, 1, False, False), (4, 16, 32, 12, 12, 1, 1, False, False), (4, 32, 32, 6, 6, 3, 2, False, False),
     (2, 480, 96, 8, 8, 1, 1, False, False), (2, 24, 40, 16, 16, 3, 1, False, False),
+    (2, 4, 16, 32, 32, 3, 2, False, False), (2, 12, 16, 16, 16, 3, 1, False, False), (2, 20, 24, 12, 12, 1, 1, False, False),
 ]
 
 
