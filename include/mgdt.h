@@ -50,6 +50,15 @@ int mgdt_conv_pack(const float* w_oihw, const float* conv_bias, const float* bn_
  * w'[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx] (what autograd's conv backward computes for stride 1, same padding).  cin / cout are
  * those of the original conv; size the buffer with mgdt_conv_packed_bytes(cout, cin, k, dtype); bias_out: fp32[cin rounded up to 16], zeroed. */
 int mgdt_conv_pack_dgrad(const float* w_oihw, int cin, int cout, int k, int phase, int dtype, void* packed_out, float* bias_out, mgdt_stream s);
+/* Many packs in a few launches (a training step re-packs every convolution after the optimizer moved the weights; the reference has no counterpart:
+ * ATen convolutions read nn.Conv2d.weight in place).  One descriptor = the arguments of one mgdt_conv_pack (mode 0) or mgdt_conv_pack_dgrad
+ * (mode 1 = stride-1 data gradient, mode 2 + phase = stride-2 phase) call; cin / cout are those of the ORIGINAL convolution. */
+typedef struct mgdt_pack_desc {
+  const float* w; const float* conv_bias; const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var;
+  float bn_eps; int32_t cin, cout, k, dtype, mode;
+  void* packed; float* bias_out;
+} mgdt_pack_desc;
+int mgdt_conv_pack_batch(const mgdt_pack_desc* descs, int n, mgdt_stream s);
 /* phase = -1: stride 1 (above).  phase = 2*py + px in 0..3 (k = 3, stride 2, even input size): the data gradient at input pixels
  * (2a + py, 2b + px) is a 3x3 same-padding convolution over dy with the taps w[py + 1 - 2*dy'][px + 1 - 2*dx'] that exist:
  * dx[:, py::2, px::2] = mgdt_conv2d_fwd(x = dy, packed(phase), k = 3, stride 1, y = that strided view). */

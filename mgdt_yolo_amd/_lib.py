@@ -23,12 +23,19 @@ VP = C.POINTER(View)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/mgdt.h declares (tests check this)
+class PackDesc(C.Structure):                  # == mgdt_pack_desc
+    _fields_ = [('w', C.c_void_p), ('conv_bias', C.c_void_p), ('bn_gamma', C.c_void_p), ('bn_beta', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p),
+                ('bn_eps', C.c_float), ('cin', C.c_int32), ('cout', C.c_int32), ('k', C.c_int32), ('dtype', C.c_int32), ('mode', C.c_int32),
+                ('packed', C.c_void_p), ('bias_out', C.c_void_p)]
+
+
 PROTOTYPES = {
     'mgdt_last_error': (C.c_char_p, []),
     'mgdt_version': (C.c_char_p, []),
     'mgdt_conv_packed_bytes': (_sz, [_i, _i, _i, _i]),
     'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
+    'mgdt_conv_pack_batch': (_i, [_vp, _i, _vp]),
     'mgdt_conv_pack_dgrad': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv_pack_direct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_direct_fwd': (_i, [VP, _i, _vp, _vp, _i, _i, _i, _i, VP, _i, _vp]),

@@ -144,6 +144,92 @@ extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, in
   return MGDT_OK;
 }
 
+// ---- batched re-pack: after an optimizer step every live packed panel of a training model is refreshed in a handful of launches instead of one (two) per
+// convolution (131 launches of ~4.5 us per step for the MSPA-GD n model).  One descriptor = one mgdt_conv_pack / mgdt_conv_pack_dgrad call.
+struct PackJob { const float* w; FoldArgs fa; int Cin, Cout, KS, CP, nchunks, NTtot, dgrad; void* out; };
+#define PACK_BATCH 16
+struct PackJobs { PackJob j[PACK_BATCH]; };
+template <typename T>
+__global__ void pack_batch_kernel(const PackJobs jobs) {
+  const PackJob& J = jobs.j[blockIdx.y];
+  constexpr int PE = Piece<T>::PE;
+  const long total = (long)J.nchunks * J.NTtot * 64 * PE;
+  const FoldArgs fa = J.fa;
+  if (fa.bias_out && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < fa.cpad; c += blockDim.x) {
+      float bo = 0.f;
+      if (c < fa.cout_real) {
+        if (fa.g) {
+          const float s = fa.g[c] / sqrtf(fa.eps + fa.var[c]);
+          bo = fa.b[c] - fa.g[c] * fa.mu[c] / sqrtf(fa.var[c] + fa.eps);
+          if (fa.cb) bo += s * fa.cb[c];
+        } else if (fa.cb) {
+          bo = fa.cb[c];
+        }
+      }
+      fa.bias_out[c] = bo;
+    }
+  const int Cin = J.Cin, Cout = J.Cout, KS = J.KS, CP = J.CP, NTtot = J.NTtot, dgrad = J.dgrad;
+  const float* __restrict__ w = J.w;
+  T* __restrict__ out = (T*)J.out;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int j = (int)(i % PE);
+    long t = i / PE;
+    int lane = (int)(t % 64);
+    t /= 64;
+    int nb = (int)(t % NTtot);
+    int kc = (int)(t / NTtot);
+    int r = lane & 15, g = lane >> 4;
+    int p = kc * 4 + g;
+    int tap = p / CP, cp = p % CP;
+    int cin = cp * PE + j, cout = nb * 16 + r;
+    float v = 0.f;
+    if (tap < KS * KS && cin < Cin && cout < Cout) {
+      if (dgrad == 1) v = w[(((long)cin * Cout + cout) * KS + (KS - 1 - tap / KS)) * KS + (KS - 1 - tap % KS)];
+      else if (dgrad >= 2) {
+        const int py = (dgrad - 2) >> 1, px = (dgrad - 2) & 1;
+        const int ky = py + 1 - 2 * (tap / KS - 1), kx = px + 1 - 2 * (tap % KS - 1);
+        v = ((unsigned)ky < 3u && (unsigned)kx < 3u) ? w[(((long)cin * Cout + cout) * 3 + ky) * 3 + kx] : 0.f;
+      }
+      else v = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
+      if (fa.g) v *= fa.g[cout] / sqrtf(fa.eps + fa.var[cout]);
+    }
+    out[i] = (T)v;
+  }
+}
+
+extern "C" int mgdt_conv_pack_batch(const mgdt_pack_desc* d, int n, mgdt_stream s) {
+  if (!d || n < 0) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_batch: null descriptor array");
+  hipStream_t st = (hipStream_t)s;
+  for (int dtype : {MGDT_F32, MGDT_BF16}) {
+    PackJobs jobs;
+    int m = 0;
+    auto flush = [&]() {
+      if (!m) return;
+      for (int q = m; q < PACK_BATCH; ++q) { jobs.j[q] = jobs.j[0]; jobs.j[q].nchunks = 0; jobs.j[q].fa.bias_out = nullptr; }     // unused slots: no work
+      if (dtype == MGDT_F32) pack_batch_kernel<float><<<dim3(32, m), 256, 0, st>>>(jobs);
+      else pack_batch_kernel<bf16><<<dim3(32, m), 256, 0, st>>>(jobs);
+      m = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      const mgdt_pack_desc& e = d[i];
+      if (e.dtype != dtype) continue;
+      if (!e.w || !e.packed || !e.bias_out) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_batch: descriptor %d has a null pointer", i);
+      if (e.mode < 0 || e.mode > 5 || (e.mode >= 2 && e.k != 3)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_pack_batch: descriptor %d mode %d", i, e.mode);
+      PackJob& J = jobs.j[m++];
+      const int gi = e.mode == 0 ? e.cin : e.cout, go = e.mode == 0 ? e.cout : e.cin;      // the data-gradient conv maps cout -> cin channels
+      conv_geometry(gi, go, e.k, dtype, &J.CP, &J.nchunks, &J.NTtot);
+      J.w = e.w; J.Cin = gi; J.Cout = go; J.KS = e.k; J.dgrad = e.mode; J.out = e.packed;
+      J.fa = e.mode == 0 ? FoldArgs{e.conv_bias, e.bn_gamma, e.bn_beta, e.bn_mean, e.bn_var, e.bn_eps, go, J.NTtot * 16, e.bias_out}
+                         : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, go, J.NTtot * 16, e.bias_out};
+      if (m == PACK_BATCH) flush();
+    }
+    flush();
+  }
+  MGDT_CHECK_LAUNCH("conv_pack_batch");
+  return MGDT_OK;
+}
+
 template <typename T, int NT, int MT>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st);   // defined in conv_igemm_inst_*.hip
 

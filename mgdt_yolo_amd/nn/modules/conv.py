@@ -46,6 +46,8 @@ class HipModule(nn.Module):
         cache = self.__dict__.setdefault('_pk', {})
         ver = (ops.PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
         hit = cache.get(key)
+        if hit is not None and hit[0] != ver and hit[0][1:] == ver[1:] and ops.pack_is_current(hit[1]):
+            hit = cache[key] = (ver, hit[1])             # the panel was refreshed in place by ops.repack_all() after the optimizer step
         if hit is None or hit[0] != ver:
             hit = (ver, build())
             cache[key] = hit

@@ -136,7 +136,7 @@ def like(t):
 # ------------------------------------------------------------------ conv
 class PackedConv:
     """Caller-owned packed weights of one convolution (BN folded) for one compute dtype."""
-    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups')
+    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', 'src', 'epoch', '__weakref__')
 
     def __init__(self, weight, conv_bias, bn, k, dtype, direct=False, groups=1):
         """weight: (cout, cin/groups, k, k) fp32 cuda; bn: None or (gamma, beta, mean, var, eps)."""
@@ -161,6 +161,53 @@ class PackedConv:
             self.bias = torch.empty((cout + 15) // 16 * 16, dtype=torch.float32, device=dev)
             _launch('conv_pack', 'mgdt_conv_pack', ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin_g, cout, k, code,
                                        ptr(self.w), ptr(self.bias), stream())
+            if groups == 1:
+                _register_pack(self, (weight, cb, g, b, mu, var, float(eps), cin_g, cout, k, code, 0))
+
+
+# ---- batched re-pack after an optimizer step -------------------------------------------------------------------------------------
+# Every packed panel built from live parameter storage registers (weakly) what it was built from.  `repack_all()` - called by the trainer
+# right after the HIP optimizer moved the weights - refreshes all panels that were valid for the step that just ran with
+# mgdt_conv_pack_batch (a handful of launches instead of one per convolution) and stamps them with the new PARAM_EPOCH; the caches that
+# hold them (HipModule._cached, the data-gradient cache below) accept a stamped panel instead of rebuilding it.
+_PACK_REGISTRY = None
+LIVE_STORAGES = set()          # storages that hold the parameters / buffers the HIP optimizer updates in place (FlatState registers its buffer)
+
+
+def _register_pack(obj, src):
+    """Only panels built directly from live parameter storage can be refreshed in place: a panel packed from a derived copy (torch.cat of two
+    branches, zero-padded rows) must be rebuilt from a fresh copy, so it is never registered."""
+    global _PACK_REGISTRY
+    import weakref
+    if not all(t is None or t.untyped_storage().data_ptr() in LIVE_STORAGES for t in src[:6]):
+        return
+    if _PACK_REGISTRY is None:
+        _PACK_REGISTRY = weakref.WeakSet()
+    obj.src, obj.epoch = src, PARAM_EPOCH[0]
+    _PACK_REGISTRY.add(obj)
+
+
+def repack_all():
+    """Refresh every registered panel that was current before the last optimizer step (PARAM_EPOCH - 1)."""
+    if not _PACK_REGISTRY:
+        return 0
+    live = [o for o in _PACK_REGISTRY if getattr(o, 'epoch', -2) == PARAM_EPOCH[0] - 1]
+    if not live:
+        return 0
+    arr = (L.PackDesc * len(live))()
+    for d, o in zip(arr, live):
+        w, cb, g, b, mu, var, eps, cin, cout, k, code, mode = o.src
+        d.w, d.conv_bias, d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = ptr(w), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var)
+        d.bn_eps, d.cin, d.cout, d.k, d.dtype, d.mode = eps, cin, cout, k, code, mode
+        d.packed, d.bias_out = ptr(o.w), ptr(o.bias)
+    _launch('conv_pack_batch', 'mgdt_conv_pack_batch', arr, len(live), stream())
+    for o in live:
+        o.epoch = PARAM_EPOCH[0]
+    return len(live)
+
+
+def pack_is_current(obj):
+    return getattr(obj, 'epoch', None) == PARAM_EPOCH[0]
 
 
 def conv_can_mfma(x, cin, cout, k, s, groups, dtype):
@@ -717,7 +764,7 @@ def bn_act_bwd(gz, y, mean, rstd, gamma, beta, act, dgamma=None, dbeta=None):
 
 class _PackedDgrad:
     """Weights of one conv packed for its stride-1 data gradient (mgdt_conv_pack_dgrad); same fields as PackedConv."""
-    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', 'key', 'owner')
+    __slots__ = ('w', 'bias', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', 'key', 'owner', 'src', 'epoch', '__weakref__')
 
     def __init__(self, weight, k, dtype, key, phase=-1):
         import weakref
@@ -729,6 +776,8 @@ class _PackedDgrad:
         self.bias = torch.empty((cin + 15) // 16 * 16, dtype=torch.float32, device=weight.device)
         wf = weight.detach().float().contiguous()
         L.check(L.lib().mgdt_conv_pack_dgrad(ptr(wf), cin, cout, k, phase, code, ptr(self.w), ptr(self.bias), stream()), 'conv_pack_dgrad')
+        if wf.data_ptr() == weight.data_ptr():                      # built from the live parameter storage: refreshable in place
+            _register_pack(self, (wf, None, None, None, None, None, 0.0, cin, cout, k, code, 1 if phase < 0 else 2 + phase))
 
 
 _DGRAD_PK = {}
@@ -743,6 +792,8 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
             and conv_can_mfma(dy, cout, cin, k, 1, 1, dy.dtype)):
         key = (PARAM_EPOCH[0], weight._version, dy.dtype)
         pk = _DGRAD_PK.get(weight.data_ptr())
+        if pk is not None and pk.owner() is weight and pk.key[1:] == key[1:] and pack_is_current(pk):
+            pk.key = key                                   # refreshed by repack_all() for this epoch
         if pk is None or pk.owner() is not weight or pk.key != key:
             pk = _DGRAD_PK[weight.data_ptr()] = _PackedDgrad(weight, k, dy.dtype, key)
         return conv2d(dy, pk, 1, ACT_NONE, out=dx, r1=dx if accumulate else None)
@@ -751,6 +802,9 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
         # four phases (input-pixel parities), each a 3x3 convolution over dy written to a strided view of dx
         key = (PARAM_EPOCH[0], weight._version, dy.dtype)
         pks = _DGRAD_PK.get((weight.data_ptr(), 2))
+        if pks is not None and pks[0].owner() is weight and pks[0].key[1:] == key[1:] and all(pack_is_current(q) for q in pks):
+            for q in pks:
+                q.key = key
         if pks is None or pks[0].owner() is not weight or pks[0].key != key:
             pks = _DGRAD_PK[(weight.data_ptr(), 2)] = [_PackedDgrad(weight, 3, dy.dtype, key, phase=ph) for ph in range(4)]
         for ph in range(4):

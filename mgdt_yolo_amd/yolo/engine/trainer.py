@@ -64,6 +64,7 @@ class FlatState:
             self.data[off:off + k].copy_(b.detach().reshape(-1))
             b.data = self.data[off:off + k].view(b.shape)
             off += k
+        ops.LIVE_STORAGES.add(self.data.untyped_storage().data_ptr())       # packed panels built from these bytes may be refreshed in place (ops.repack_all)
         self.momentum_buf = torch.zeros(self.n_param, dtype=torch.float32, device=dev)
         self.ema = self.data.clone()
         self.steps = 0                     # optimizer steps taken (= ModelEMA.updates)
@@ -179,6 +180,7 @@ class DetectionTrainer:
         st.steps += 1
         d = self.ema_decay * (1 - math.exp(-st.steps / self.ema_tau))      # torch_utils.py:342
         ops.ema_update(st.ema, st.data, d)
+        ops.repack_all()                            # the packed panels of this step, refreshed for the next one in a few launches
 
     # ---- captured step -------------------------------------------------------------------------------------------------------------
     def _graph_ok(self):
@@ -194,6 +196,7 @@ class DetectionTrainer:
         self.model.backward(grads)
         clip = ops.grad_clip_coef(st.grad, 10.0)
         ops.sgd_ema_step_dev(st.data[:st.n_param], st.grad, st.momentum_buf, st.wd, st.ema, st.data, S['hyper'], True, False, clip)
+        ops.repack_all()                            # next step's packed weights, all convolutions in a few launches
         S['out5'] = ls.out5
 
     def _graph_step(self, batch):
