@@ -281,6 +281,12 @@ int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, int stride,
 size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k);
 int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
                     int accumulate, void* ws, int dtype, mgdt_stream s);
+/* Deferred final sums: mgdt_conv_wgrad with dw_oihw == NULL (and dbias == NULL) leaves its per-split partial sums in ws
+ * ([mgdt_conv_wgrad_splits(cin, cout, k)][cout][cin][k*k] fp32); mgdt_wgrad_final_batch then finishes many convolutions in one launch, each in the
+ * same fixed order as the immediate form (the results are bit-identical).  The caller keeps every ws alive until the batch has run. */
+int mgdt_conv_wgrad_splits(int cin, int cout, int k);
+typedef struct mgdt_wgrad_final_desc { const float* partial; float* dw; long n; int32_t nsplit; int32_t accumulate; } mgdt_wgrad_final_desc;
+int mgdt_wgrad_final_batch(const mgdt_wgrad_final_desc* descs, int n, mgdt_stream s);
 int mgdt_add_fwd(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int dtype, mgdt_stream s);
 int mgdt_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, mgdt_stream s);
 int mgdt_nearest_bwd(const mgdt_view* gy, const mgdt_view* gx, int dtype, mgdt_stream s);

@@ -29,6 +29,10 @@ class PackDesc(C.Structure):                  # == mgdt_pack_desc
                 ('packed', C.c_void_p), ('bias_out', C.c_void_p)]
 
 
+class WgradFinalDesc(C.Structure):            # == mgdt_wgrad_final_desc
+    _fields_ = [('partial', C.c_void_p), ('dw', C.c_void_p), ('n', C.c_long), ('nsplit', C.c_int32), ('accumulate', C.c_int32)]
+
+
 PROTOTYPES = {
     'mgdt_last_error': (C.c_char_p, []),
     'mgdt_version': (C.c_char_p, []),
@@ -36,6 +40,8 @@ PROTOTYPES = {
     'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
     'mgdt_conv_pack_batch': (_i, [_vp, _i, _vp]),
+    'mgdt_conv_wgrad_splits': (_i, [_i, _i, _i]),
+    'mgdt_wgrad_final_batch': (_i, [_vp, _i, _vp]),
     'mgdt_conv_pack_dgrad': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv_pack_direct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_direct_fwd': (_i, [VP, _i, _vp, _vp, _i, _i, _i, _i, VP, _i, _vp]),

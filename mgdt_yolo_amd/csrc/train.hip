@@ -459,7 +459,11 @@ extern "C" size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k) {
 
 extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
                                int accumulate, void* ws, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(dy) || !dw_oihw || !ws) MGDT_FAIL(MGDT_BAD_ARG, "conv_wgrad: null/empty argument");
+  if (!view_ok(x) || !view_ok(dy) || !ws) MGDT_FAIL(MGDT_BAD_ARG, "conv_wgrad: null/empty argument");
+  // dw_oihw == NULL: partial sums only (ws keeps [mgdt_conv_wgrad_splits][cout][cin][k*k] fp32); mgdt_wgrad_final_batch adds them up later for many
+  // convolutions in one launch.  Not for the generic (non-NHWC / channels % 4) path and not together with dbias (which reuses ws).
+  const bool partial_only = dw_oihw == nullptr;
+  if (partial_only && (dbias || x->sc != 1 || x->c % 4 || dy->c % 4)) MGDT_FAIL(MGDT_BAD_ARG, "conv_wgrad: partial-only mode needs NHWC views with channels %% 4 == 0 and no dbias");
   hipStream_t st = (hipStream_t)s;
   if (dy->sc != 1 || x->n != dy->n) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_wgrad: dy must be an NHWC view with the batch of x");
   if (x->sc != 1 || x->c % 4 || dy->c % 4) {   // generic path: fp32 input of any layout (the image), no fused x2
@@ -487,13 +491,59 @@ extern "C" int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mg
     MGDT_DISPATCH_DTYPE(dtype, (conv_wgrad_partial_kernel<T><<<grid, 256, 0, st>>>(*x, b, *dy, k, stride, (float*)ws, nsplit)));
   }
   long n = (long)dy->c * x->c * k * k;
-  wgrad_final_kernel<<<cdiv(n, 64), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
+  if (!partial_only) wgrad_final_kernel<<<cdiv(n, 64), 256, 0, st>>>((const float*)ws, n, dw_oihw, accumulate, nsplit);
   if (dbias) {
     dim3 g2(cdiv(dy->c, red_cw(dy->c)), RED_SPLITS);
     MGDT_DISPATCH_DTYPE(dtype, (bias_grad_partial_kernel<T><<<g2, 256, 0, st>>>(*dy, (double*)ws)));
     bias_grad_final_kernel<<<cdiv(dy->c, FIN_CW), 256, 0, st>>>((const double*)ws, dy->c, dbias, accumulate);
   }
   MGDT_CHECK_LAUNCH("conv_wgrad");
+  return MGDT_OK;
+}
+
+extern "C" int mgdt_conv_wgrad_splits(int cin, int cout, int k) { return wgrad_splits(cin, cout, k); }
+
+// The final sums of many weight gradients in one launch (a training step has ~60 of them, each a ~7 us launch of its own otherwise): job j adds the
+// nsplit partial rows of its convolution in the fixed order of wgrad_final_kernel (4 interleaved sub-sums, then their sum).
+struct WgFinalJob { const float* partial; float* dw; long n; int nsplit, accumulate; };
+#define WGF_BATCH 32
+struct WgFinalJobs { WgFinalJob j[WGF_BATCH]; };
+__global__ __launch_bounds__(256) void wgrad_final_batch_kernel(const WgFinalJobs jobs) {
+  const WgFinalJob J = jobs.j[blockIdx.y];
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+  for (long base = blockIdx.x * 64L; base < J.n; base += gridDim.x * 64L) {
+    const long i = base + el;
+    float a = 0.f;
+    if (i < J.n) {
+#pragma unroll 8
+      for (int k = part; k < J.nsplit; k += 4) a += J.partial[(long)k * J.n + i];
+    }
+    __syncthreads();
+    red[part][el] = a;
+    __syncthreads();
+    if (part == 0 && i < J.n) {
+      const float t = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+      J.dw[i] = J.accumulate ? J.dw[i] + t : t;
+    }
+  }
+}
+extern "C" int mgdt_wgrad_final_batch(const mgdt_wgrad_final_desc* d, int n, mgdt_stream s) {
+  if (!d || n < 0) MGDT_FAIL(MGDT_BAD_ARG, "wgrad_final_batch: null descriptor array");
+  hipStream_t st = (hipStream_t)s;
+  for (int i0 = 0; i0 < n; i0 += WGF_BATCH) {
+    WgFinalJobs jobs;
+    const int m = std::min(WGF_BATCH, n - i0);
+    for (int q = 0; q < WGF_BATCH; ++q) {
+      const mgdt_wgrad_final_desc& e = d[i0 + (q < m ? q : 0)];
+      if (!e.partial || !e.dw || e.n <= 0 || e.nsplit < 1) MGDT_FAIL(MGDT_BAD_ARG, "wgrad_final_batch: descriptor %d", i0 + q);
+      jobs.j[q] = WgFinalJob{e.partial, e.dw, q < m ? e.n : 0, e.nsplit, e.accumulate};
+    }
+    long nmax = 0;
+    for (int q = 0; q < m; ++q) nmax = std::max(nmax, jobs.j[q].n);
+    wgrad_final_batch_kernel<<<dim3((unsigned)std::min<long>(cdiv(nmax, 64), 1024), m), 256, 0, st>>>(jobs);       // workgroups past a job's end leave at once
+  }
+  MGDT_CHECK_LAUNCH("wgrad_final_batch");
   return MGDT_OK;
 }
 

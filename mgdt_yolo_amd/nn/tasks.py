@@ -117,6 +117,10 @@ class BaseModel(nn.Module):
         adjoint kernels and fills `.grad` of its parameters (overwrite semantics); gradients of tensors with several
         consumers (the save-list) are summed with the HIP add kernel.  `layer_done(i)` is called after layer i's kernels are queued (the
         trainer hangs its bucketed gradient all-reduce on it)."""
+        with ops.defer_wgrad():          # final sums of all weight gradients in one launch at the end (or at the all-reduce bucket boundaries)
+            self._backward_layers(head_grads, layer_done)
+
+    def _backward_layers(self, head_grads, layer_done):
         n = len(self.model)
         pend = {n - 1: head_grads}
         for m in reversed(list(self.model)):

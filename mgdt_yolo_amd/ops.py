@@ -826,6 +826,7 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         copy(x, x4[:, :c])
         dw4 = torch.empty((dw.shape[0], 4, k, k), dtype=torch.float32, device=x.device)
         conv_wgrad(x4, dy, k, stride, dw4, dbias=dbias)
+        flush_wgrad()                                  # dw4 is read right below
         copy(dw4[:, :c], dw)
         return
     _same(x, dy, x2)
@@ -834,7 +835,39 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         b, ci, h, w = x.shape
         _META['conv_wgrad'] = dict(shape=(b, ci, h, w, dy.shape[1], k, stride), flops=2.0 * dy.numel() * ci * k * k,
                                    bytes=float(x.numel() * x.element_size() + dy.numel() * dy.element_size()))
-    _launch('conv_wgrad', 'mgdt_conv_wgrad', vp(x), vp(x2), vp(dy), k, stride, ptr(dw), ptr(dbias), int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
+    if _WGRAD_DEFER[0] > 0 and accumulate:
+        flush_wgrad()                                  # an accumulating gradient must see the value the pending jobs will write
+    defer = (_WGRAD_DEFER[0] > 0 and dbias is None and not accumulate and is_nhwc(x) and x.shape[1] % 4 == 0 and dy.shape[1] % 4 == 0 and dw.is_contiguous())
+    _launch('conv_wgrad', 'mgdt_conv_wgrad', vp(x), vp(x2), vp(dy), k, stride, None if defer else ptr(dw), ptr(dbias), int(accumulate), ptr(ws), dtype_code(x.dtype), stream())
+    if defer:
+        _WGRAD_PENDING.append((ws, dw, dw.numel(), lib.mgdt_conv_wgrad_splits(x.shape[1], dy.shape[1], k)))
+
+
+# Deferred final sums of the weight gradients: inside `with defer_wgrad():` (the model's reverse pass) a convolution leaves its per-split partial sums
+# in its workspace and `flush_wgrad()` adds them up for all pending convolutions in one launch (bit-identical to the immediate form).
+_WGRAD_DEFER = [0]
+_WGRAD_PENDING = []
+
+
+class defer_wgrad:
+    def __enter__(self):
+        _WGRAD_DEFER[0] += 1
+
+    def __exit__(self, *exc):
+        _WGRAD_DEFER[0] -= 1
+        if _WGRAD_DEFER[0] == 0:
+            flush_wgrad()
+        return False
+
+
+def flush_wgrad():
+    if not _WGRAD_PENDING:
+        return
+    arr = (L.WgradFinalDesc * len(_WGRAD_PENDING))()
+    for d, (ws, dw, n, nsplit) in zip(arr, _WGRAD_PENDING):
+        d.partial, d.dw, d.n, d.nsplit, d.accumulate = ptr(ws), ptr(dw), n, nsplit, 0
+    _launch('wgrad_final_batch', 'mgdt_wgrad_final_batch', arr, len(_WGRAD_PENDING), stream())
+    _WGRAD_PENDING.clear()
 
 
 def add(a, b, out=None):

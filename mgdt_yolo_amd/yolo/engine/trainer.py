@@ -100,6 +100,7 @@ class BucketedAllReduce:
         import torch.distributed as dist
         for lo, a, b in self.slices:
             if lo == i and b > a:
+                ops.flush_wgrad()                      # the slice must hold finished weight gradients before it is sent
                 self.work.append(dist.all_reduce(self.state.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
