@@ -65,10 +65,11 @@ class Bottleneck(HipModule):
         t = self.cv1.run(x, x2=x2)
         return self.cv2.run(t, out=out, r1=x if self.add else None, r2=x2 if self.add else None)
 
-    def backward(self, gz):
-        """Returns d/d(x [+ x2]) (the same tensor is the gradient of both addends)."""
-        gx = self.cv1.backward(self.cv2.backward(gz))
-        return ops.add(gx, gz, out=gx) if self.add else gx
+    def backward(self, gz, acc_into=None):
+        """Returns d/d(x [+ x2]) (the same tensor is the gradient of both addends); with `acc_into` the result is ADDED to that view instead
+        (the shortcut's gradient and the accumulation ride in the data-gradient convolution's epilogue: no separate add launches)."""
+        gmid = self.cv2.backward(gz)
+        return self.cv1.backward(gmid, dx_out=acc_into, acc=acc_into is not None, r2=gz if self.add else None)
 
     def forward(self, x):
         return self.run(x)
@@ -109,9 +110,7 @@ class C2f(HipModule):
         c, n = self.c, len(self.m)
         gcat = self.cv2.backward(g)                                   # grad of the concat buffer
         for j in reversed(range(n)):                                  # bottleneck j: slot 1+j -> slot 2+j
-            gin = self.m[j].backward(gcat[:, (2 + j) * c:(3 + j) * c])
-            dst = gcat[:, (1 + j) * c:(2 + j) * c]
-            ops.add(dst, gin, out=dst)
+            self.m[j].backward(gcat[:, (2 + j) * c:(3 + j) * c], acc_into=gcat[:, (1 + j) * c:(2 + j) * c])
         return self.cv1.backward(gcat[:, :2 * c])
 
 
@@ -202,11 +201,13 @@ class MSPA_C2f(HipModule):
         gx = ops.new_act(xshape[0], xshape[1], xshape[2], xshape[3], g.dtype, g.device)
         sl = lambda t, i: t[:, i * wd:(i + 1) * wd]
         for j in reversed(range(n)):                                 # bottleneck j: slot s-2+j (+ pending for j == 0) -> slot s-1+j
+            if j > 0:
+                self.bottleneck[j].backward(sl(gcat, s - 1 + j), acc_into=sl(gcat, s - 2 + j))
+                continue
             gin = self.bottleneck[j].backward(sl(gcat, s - 1 + j))
             dst = sl(gcat, s - 2 + j)
             ops.add(dst, gin, out=dst)
-            if j == 0:
-                ops.copy(gin, sl(gx, s - 1))                        # the pending addend spx[s-1]
+            ops.copy(gin, sl(gx, s - 1))                            # the pending addend spx[s-1]
         for i in reversed(range(1, s - 1)):                          # convs[i](slot i-1 + spx[i])
             gi = self.convs[i].backward(sl(gcat, i), dx_out=sl(gx, i))
             dst = sl(gcat, i - 1)

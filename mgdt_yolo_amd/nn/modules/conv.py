@@ -131,9 +131,10 @@ class Conv(HipModule):
         self._save_ctx((x, x2, y, mean, rstd, k, s))
         return z
 
-    def backward(self, gz, need_dx=True, dx_out=None):
+    def backward(self, gz, need_dx=True, dx_out=None, acc=False, r2=None):
         """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx
-        (written into the view `dx_out` when given)."""
+        (written into the view `dx_out` when given; `acc`: added to what dx_out holds; `r2`: one more addend, e.g. a shortcut's gradient -
+        both fused into the data-gradient convolution's epilogue)."""
         if self.conv.groups != 1:
             raise NotImplementedError('grouped / depth-wise Conv has no backward kernels')
         x, x2, y, mean, rstd, k, s = self._ctx.pop()
@@ -146,7 +147,7 @@ class Conv(HipModule):
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
-        return ops.conv_dgrad(dy, self.conv.weight, k, s, dx)
+        return ops.conv_dgrad(dy, self.conv.weight, k, s, dx, accumulate=bool(acc and dx_out is not None), r2=r2)
 
     def forward_fuse(self, x):
         """After BaseModel.fuse(): `bn` is gone and `conv` carries the folded weight + bias (conv.py:40-42)."""

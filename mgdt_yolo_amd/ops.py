@@ -783,10 +783,13 @@ class _PackedDgrad:
 _DGRAD_PK = {}
 
 
-def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
+def conv_dgrad(dy, weight, k, stride, dx, accumulate=False, r2=None):
     """dx (+)= d loss / d x of conv(x, weight).  Stride 1 on NHWC maps: the forward MFMA kernel on the flipped / transposed weights
-    (re-packed once per optimizer epoch); otherwise the direct kernel."""
+    (re-packed once per optimizer epoch); otherwise the direct kernel.  `r2`: one more addend shaped like dx (a shortcut's gradient), fused
+    into the convolution's epilogue where the MFMA path applies."""
     cout, cin = weight.shape[0], weight.shape[1]
+    res = [t for t in (dx if accumulate else None, r2) if t is not None]
+    r1_, r2_ = (res + [None, None])[:2]
     if (stride == 1 and (weight.dim() == 2 and k == 1 or weight.dim() == 4 and weight.shape[2] == k) and k in (1, 3) and dx.dtype == dy.dtype
             and is_nhwc(dx) and cin % 4 == 0
             and conv_can_mfma(dy, cout, cin, k, 1, 1, dy.dtype)):
@@ -796,7 +799,7 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
             pk.key = key                                   # refreshed by repack_all() for this epoch
         if pk is None or pk.owner() is not weight or pk.key != key:
             pk = _DGRAD_PK[weight.data_ptr()] = _PackedDgrad(weight, k, dy.dtype, key)
-        return conv2d(dy, pk, 1, ACT_NONE, out=dx, r1=dx if accumulate else None)
+        return conv2d(dy, pk, 1, ACT_NONE, out=dx, r1=r1_, r2=r2_)
     if (stride == 2 and k == 3 and weight.dim() == 4 and weight.shape[2] == 3 and dx.dtype == dy.dtype and is_nhwc(dx) and cin % 4 == 0
             and dx.shape[2] == 2 * dy.shape[2] and dx.shape[3] == 2 * dy.shape[3] and conv_can_mfma(dy, cout, cin, 3, 1, 1, dy.dtype)):
         # four phases (input-pixel parities), each a 3x3 convolution over dy written to a strided view of dx
@@ -809,11 +812,12 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False):
             pks = _DGRAD_PK[(weight.data_ptr(), 2)] = [_PackedDgrad(weight, 3, dy.dtype, key, phase=ph) for ph in range(4)]
         for ph in range(4):
             sub = dx[:, :, ph >> 1::2, ph & 1::2]
-            conv2d(dy, pks[ph], 1, ACT_NONE, out=sub, r1=sub if accumulate else None)
+            conv2d(dy, pks[ph], 1, ACT_NONE, out=sub, r1=None if r1_ is None else r1_[:, :, ph >> 1::2, ph & 1::2],
+                   r2=None if r2_ is None else r2_[:, :, ph >> 1::2, ph & 1::2])
         return dx
     _same(dy, dx)
     _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
-    return dx
+    return dx if r2 is None else add(dx, r2, out=dx)
 
 
 def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
