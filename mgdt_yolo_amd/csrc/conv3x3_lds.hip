@@ -1,0 +1,247 @@
+// 3x3 stride-1 convolution (bf16) with the ACTIVATIONS staged in LDS - for the compute-heavy layers (64-128 input channels on 80x80 / 40x40 maps: the
+// Detect branches) where conv_igemm_kernel, which feeds the MFMA B operand straight from global memory, re-requests every input pixel nine times
+// (once per tap) through the texture path and ends up address-bound at 330-430 TFLOP/s.
+// Reference: Conv.forward_fuse (nn/modules/conv.py:40-42) = act(conv(x)) with BatchNorm folded into the packed weights (mgdt_conv_pack).
+//
+//   * persistent workgroups (one per CU, 4 waves): a workgroup owns NBW cout blocks; their weight panel (the same fragment-ordered layout conv_igemm uses,
+//     1 KB per [K chunk][cout block]) is loaded into LDS ONCE and stays there for all the pixel tiles the workgroup walks;
+//   * a tile = 16x16 output pixels; its 18x18 input region (zero outside the image) sits in LDS as [pixel][cin] rows with a 16-byte pad, so the B fragment of
+//     lane (r, g) - 8 consecutive channels of pixel r for the tap the K piece belongs to - is one ds_read_b128 at pixel-row address + a per-piece constant
+//     (table in LDS); a tap costs nothing but that constant;
+//   * wave w owns tile rows 4w .. 4w+3 (MT = 4 pixel groups of 16) and all NBW cout blocks: NBW + 4 fragment reads feed 4*NBW MFMAs per K step; fragments are
+//     double-buffered in registers so the LDS reads of step k+1 are in flight under the MFMAs of step k;
+//   * the next tile's region is requested into registers before the current tile's MFMAs and written to LDS after them.
+#include <vector>
+
+#include "common.h"
+
+#define C3_OOB ((int)0x80000000)
+#define C3_TW 16
+#define C3_RW 18
+#define C3_RP (C3_RW * C3_RW)          // 324 region pixels
+#define C3_MAXI 14                     // 16-byte items a thread stages per tile: 324 * (Cin / 8) / 256, Cin <= 80 -> 12.7
+
+struct C3Args {
+  const char* x; int xsn, xsh, xsw; uint32_t x_bytes;
+  char* y; int ysn, ysh, ysw; uint32_t y_bytes;
+  const char* wpk; const float* bias;
+  int N, H, W, Cin, Cout, CP, nchunks, NTtot, ncg, tiles_x, tiles_per_img, ntiles, XP, act;
+  FastDiv fd_tpi, fd_tx, fd_cp;
+  unsigned long long* dbg;       // MGDT_C3_DBG: per workgroup {start, weights staged, sum(commit), sum(mfma), sum(epilogue), tiles} in 10 ns ticks
+};
+
+template <int ACT> __device__ __forceinline__ float c3_act(float v) {
+  if (ACT == MGDT_ACT_SILU) return v * fast_sigmoid(v);
+  if (ACT == MGDT_ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+// NCH > 0: the K loop is fully unrolled (no back edge: the compiler can keep the next step's LDS reads in flight under this step's MFMAs; with a run-time
+// trip count it waited for every fragment right before its first use and the single wave per SIMD had nothing to hide that latency behind)
+template <int NBW, int ACT, int NCH>
+__global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char c3_lds[];
+  int* tab = (int*)c3_lds;                                          // [nchunks * 4] byte offset of piece p inside the region, relative to the pixel's row
+  char* wl = c3_lds + (((size_t)a.nchunks * 16 + 15) & ~(size_t)15);
+  char* xs = wl + (size_t)a.nchunks * NBW * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = blockIdx.x % a.ncg, w0 = blockIdx.x / a.ncg, wstep = gridDim.x / a.ncg;      // cout group, first tile, tile step of this workgroup
+  const int nb0 = cg * NBW;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+
+  // ---- once per workgroup: piece table and the weight panel of its cout blocks
+  for (int p = tid; p < a.nchunks * 4; p += 256) {
+    const int tap = (int)fdiv((uint32_t)p, a.fd_cp), cp = p - tap * a.CP;
+    tab[p] = tap < 9 ? ((tap / 3) * C3_RW + (tap % 3)) * a.XP + cp * 16 : 0;       // padding pieces carry zero weights: any in-range address
+  }
+  for (int i = tid; i < a.nchunks * NBW * 64; i += 256) {
+    const int kc = i / (NBW * 64), rem = i - kc * NBW * 64, bw = rem >> 6, ln = rem & 63;
+    const bool ok = nb0 + bw < a.NTtot;
+    const uint4 v = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * 64 + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
+    *(uint4*)(wl + (size_t)i * 16) = v;
+  }
+  f32x4 bias[NBW];
+#pragma unroll
+  for (int bw = 0; bw < NBW; ++bw) bias[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nb0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging of one tile's input region: item = (region pixel, 8-channel piece)
+  const int nitems = C3_RP * a.CP;
+  uint4 stage[C3_MAXI];
+  auto issue = [&](int t) {
+    const int n = (int)fdiv((uint32_t)t, a.fd_tpi), rt = t - n * a.tiles_per_img;
+    const int tyi = (int)fdiv((uint32_t)rt, a.fd_tx), txi = rt - tyi * a.tiles_x;
+    const int iy0 = tyi * C3_TW - 1, ix0 = txi * C3_TW - 1;
+#pragma unroll
+    for (int u = 0; u < C3_MAXI; ++u) {
+      const int it = tid + u * 256;
+      const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
+      const int py = pix / C3_RW, px = pix - py * C3_RW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = it < nitems && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      stage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (uint32_t)(n * a.xsn + iy * a.xsh + ix * a.xsw + c8 * 16) : (uint32_t)C3_OOB, 0, 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < C3_MAXI; ++u) {
+      const int it = tid + u * 256;
+      if (it < nitems) {
+        const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
+        *(uint4*)(xs + pix * a.XP + c8 * 16) = stage[u];
+      }
+    }
+  };
+
+  const char* const wlane = wl + lane * 16;
+  int bbase[4];                                                      // region row address of this lane's pixel in the wave's four pixel groups
+#pragma unroll
+  for (int m = 0; m < 4; ++m) bbase[m] = ((wave * 4 + m) * C3_RW + r) * a.XP;
+
+  // every global load issued so far (bias, weights) is retired HERE: otherwise the compiler, unable to order them against the prefetches that are
+  // pending at the loop's back edge, waits for vmcnt(0) - i.e. for the NEXT tile's prefetch - in front of the first MFMA of every tile
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  unsigned long long T0 = 0, Tc = 0, Tm = 0, Te = 0, tl = 0, ntl = 0;
+  if (a.dbg) { T0 = __builtin_amdgcn_s_memrealtime(); tl = T0; }
+  int t = w0;
+  if (t < a.ntiles) issue(t);
+  while (t < a.ntiles) {
+    __syncthreads();                                                 // the previous tile's fragments have been read (first pass: table + weights written)
+    commit();
+    __syncthreads();
+    if (a.dbg) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); Tc += n_ - tl; tl = n_; }
+    const int tn = t + wstep;
+    if (tn < a.ntiles) issue(tn);                                    // in flight under this tile's MFMAs
+
+    f32x4 acc[NBW][4];
+#pragma unroll
+    for (int bw = 0; bw < NBW; ++bw)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[bw][m] = bias[bw];
+    bf16x8 A[2][NBW], B[2][4];
+    auto load_frags = [&](int kc, int buf) {
+      const int off = tab[kc * 4 + g];
+#pragma unroll
+      for (int bw = 0; bw < NBW; ++bw) A[buf][bw] = *(const bf16x8*)(wlane + (size_t)(kc * NBW + bw) * 1024);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) B[buf][m] = *(const bf16x8*)(xs + bbase[m] + off);
+    };
+    load_frags(0, 0);
+    if (NCH > 0) {
+#pragma unroll
+      for (int kc = 0; kc < NCH; ++kc) {
+        if (kc + 1 < NCH) load_frags(kc + 1, (kc + 1) & 1);
+#pragma unroll
+        for (int bw = 0; bw < NBW; ++bw)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc & 1][bw], B[kc & 1][m], acc[bw][m], 0, 0, 0);
+      }
+    } else {
+      for (int kc = 0; kc < a.nchunks; kc += 2) {
+        if (kc + 1 < a.nchunks) load_frags(kc + 1, 1);
+#pragma unroll
+        for (int bw = 0; bw < NBW; ++bw)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][bw], B[0][m], acc[bw][m], 0, 0, 0);
+        if (kc + 1 < a.nchunks) {
+          if (kc + 2 < a.nchunks) load_frags(kc + 2, 0);
+#pragma unroll
+          for (int bw = 0; bw < NBW; ++bw)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][bw], B[1][m], acc[bw][m], 0, 0, 0);
+        }
+      }
+    }
+
+    if (a.dbg) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); Tm += n_ - tl; tl = n_; }
+    // epilogue: lane (r, g) holds couts 4g .. 4g+3 of pixel r: one 8-byte store per (cout block, pixel group)
+    {
+      const int n = (int)fdiv((uint32_t)t, a.fd_tpi), rt = t - n * a.tiles_per_img;
+      const int tyi = (int)fdiv((uint32_t)rt, a.fd_tx), txi = rt - tyi * a.tiles_x;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int oy = tyi * C3_TW + wave * 4 + m, ox = txi * C3_TW + r;
+        const bool pin = oy < a.H && ox < a.W;
+        const int po = n * a.ysn + oy * a.ysh + ox * a.ysw;
+#pragma unroll
+        for (int bw = 0; bw < NBW; ++bw) {
+          const int co = (nb0 + bw) * 16 + 4 * g;
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)c3_act<ACT>(acc[bw][m][j]);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, o), yrs,
+                                                (pin && co < a.Cout) ? (uint32_t)(po + co * 2) : (uint32_t)C3_OOB, 0, 0);
+        }
+      }
+    }
+    if (a.dbg) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); Te += n_ - tl; tl = n_; ++ntl; }
+    t = tn;
+  }
+  if (a.dbg && tid == 0) { unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6; d[0] = T0; d[1] = tl; d[2] = Tc; d[3] = Tm; d[4] = Te; d[5] = ntl; }
+}
+
+// true when the layer is launched here (the caller returns), false: conv_igemm takes it
+bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st) {
+  static const int mode = getenv("MGDT_CONV3_LDS") ? atoi(getenv("MGDT_CONV3_LDS")) : 1;      // experiment knob: 0 = never
+  if (!mode) return false;
+  const int Cin = x->c, Cout = y->c;
+  if (Cin % 8 || Cin < 32 || Cin > 80 || Cout % 4 || Cout < 32 || (act != MGDT_ACT_SILU && act != MGDT_ACT_NONE && act != MGDT_ACT_RELU)) return false;
+  const long M = (long)x->n * x->h * x->w;
+  if (M < 16 * 1024 || x->h < 16 || x->w < 16) return false;                                    // small maps: the igemm kernel's finer tiles fill the chip better
+  const long extx = ((long)(x->n - 1) * x->sn + (long)(x->h - 1) * x->sh + (long)(x->w - 1) * x->sw + x->c) * 2;
+  const long exty = ((long)(y->n - 1) * y->sn + (long)(y->h - 1) * y->sh + (long)(y->w - 1) * y->sw + y->c) * 2;
+  if (extx >= 0x7fffffffL || exty >= 0x7fffffffL) return false;
+  C3Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const char*)x->p; a.xsn = (int)(x->sn * 2); a.xsh = (int)(x->sh * 2); a.xsw = (int)(x->sw * 2); a.x_bytes = (uint32_t)extx;
+  a.y = (char*)y->p; a.ysn = (int)(y->sn * 2); a.ysh = (int)(y->sh * 2); a.ysw = (int)(y->sw * 2); a.y_bytes = (uint32_t)exty;
+  a.wpk = (const char*)packed_w; a.bias = bias;
+  a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = Cin; a.Cout = Cout; a.CP = CP; a.nchunks = nchunks; a.NTtot = NTtot; a.act = act;
+  a.tiles_x = cdiv(x->w, C3_TW);
+  a.tiles_per_img = a.tiles_x * cdiv(x->h, C3_TW);
+  a.ntiles = x->n * a.tiles_per_img;
+  a.XP = Cin * 2 + 16;
+  if (C3_RP * CP > 256 * C3_MAXI) return false;
+  a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
+  // every cout block in ONE workgroup (the input region is then staged once per tile); layers whose whole weight panel does not fit next to the
+  // region stay on the igemm kernel: splitting the couts over workgroups re-reads the input per group and measured no faster
+  const int NBW = NTtot;
+  if (NBW != 2 && NBW != 3 && NBW != 4 && NBW != 6) return false;
+  a.ncg = 1;
+  const size_t lds = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * 1024 + (size_t)C3_RP * a.XP;
+  if (lds > 160 * 1024) return false;
+  int nwg = 256 / a.ncg * a.ncg;                                                                // one workgroup per CU, a multiple of the cout groups
+  nwg = (int)std::min<long>(nwg, (long)a.ntiles * a.ncg);
+  nwg = nwg / a.ncg * a.ncg;
+  if (nwg < a.ncg) return false;
+#define C3_LAUNCH(NB, ACTV)                                                                                          \
+  {                                                                                                                  \
+    static bool attr = false, attr18 = false;                                                                        \
+    if (nchunks == 18) {                                                                                             \
+      if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 18><<<nwg, 256, lds, st>>>(a);                                                    \
+    } else {                                                                                                         \
+      if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 0><<<nwg, 256, lds, st>>>(a);                                                     \
+    }                                                                                                                \
+  }
+#define C3_ACT(NB) \
+  if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU) else C3_LAUNCH(NB, MGDT_ACT_NONE)
+  static unsigned long long* dbgbuf = nullptr;
+  if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);
+  a.dbg = dbgbuf;
+  if (NBW == 6) { C3_ACT(6) } else if (NBW == 4) { C3_ACT(4) } else if (NBW == 3) { C3_ACT(3) } else { C3_ACT(2) }
+#undef C3_ACT
+#undef C3_LAUNCH
+  if (dbgbuf) {
+    std::vector<unsigned long long> h(256 * 6);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0; double c = 0, m = 0, e = 0, nt = 0;
+    for (int i = 0; i < nwg; ++i) { t0 = std::min(t0, h[i * 6]); t1 = std::max(t1, h[i * 6 + 1]); c += h[i * 6 + 2]; m += h[i * 6 + 3]; e += h[i * 6 + 4]; nt += h[i * 6 + 5]; }
+    fprintf(stderr, "conv3x3_lds cin %d cout %d %dx%d: %d wgs, %d tiles, span %.1f us; per tile (us): wait+commit %.2f mfma %.2f epilogue %.2f\n", Cin, Cout, x->h, x->w, nwg,
+            a.ntiles, (t1 - t0) * 0.01, c / nt * 0.01, m / nt * 0.01, e / nt * 0.01);
+  }
+  return true;
+}

@@ -230,6 +230,8 @@ extern "C" int mgdt_conv_pack_batch(const mgdt_pack_desc* d, int n, mgdt_stream 
   return MGDT_OK;
 }
 
+bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st);
+
 template <typename T, int NT, int MT>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st);   // defined in conv_igemm_inst_*.hip
 
@@ -291,6 +293,12 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   if (M > 0x7fffffffL - (1 << 20)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: problem too large");
   a.M = (int)M; a.HoWo = Ho * Wo;
   a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
+  // plain 3x3 stride-1 bf16 layers with 32-80 input channels on large maps: the LDS-staged kernel (conv3x3_lds.hip)
+  if (dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
+      mgdt_conv3x3_lds_launch(x, y, packed_w, bias, act, a.CP, a.nchunks, a.NTtot, (hipStream_t)s)) {
+    MGDT_CHECK_LAUNCH("conv2d(3x3 lds)");
+    return MGDT_OK;
+  }
 
   // tile choice: NT = cout blocks per workgroup - as many as divide NTtot and keep the whole weight panel in LDS
   // (activations are then read NTtot/NT times; once when NT == NTtot), fewer when the grid would starve the 256 CUs
