@@ -165,7 +165,7 @@ def roofline_of(prof_rows, reps, step_ms, graph, args):
     else:
         ach = bytes_l / avg_s / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-    kern = {'conv2d_fwd': 'conv_igemm_kernel', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
+    kern = {'conv2d_fwd': 'conv_igemm_kernel (+ conv3x3_lds_kernel for the 64->96 Detect-branch 3x3)', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
             'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel', 'csp_block_fwd': 'csp_block_kernel'}.get(name, name)
     traffic, tsrc, tat = None, None, None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected

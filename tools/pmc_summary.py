@@ -28,7 +28,7 @@ print(f'{"kernel":<72}{"launches":>9}{"read MB":>10}{"write MB":>10}{"total MB":
 for k, n, r, wr in sorted(rows, key=lambda t: -(t[2] + t[3]) * t[1]):
     if (r + wr) * n > 1e6:
         print(f'{k[:70]:<72}{n:>9}{r / 1e6:>10.2f}{wr / 1e6:>10.2f}{(r + wr) / 1e6:>10.2f}')
-conv = [(n, r, wr) for k, n, r, wr in rows if 'conv_igemm_kernel' in k]
+conv = [(n, r, wr) for k, n, r, wr in rows if 'conv_igemm_kernel' in k or 'conv3x3_lds_kernel' in k]      # the conv2d_fwd family of bench.py's roofline
 if conv:
     tot = sum(n for n, _, _ in conv)
     by = sum(n * (r + wr) for n, r, wr in conv) / tot
