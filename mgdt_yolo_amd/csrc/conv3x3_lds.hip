@@ -18,7 +18,6 @@
 #define C3_OOB ((int)0x80000000)
 #define C3_TW 16
 #define C3_RW 18
-#define C3_RP (C3_RW * C3_RW)          // 324 region pixels
 #define C3_MAXI 14                     // 16-byte items a thread stages per tile: 324 * (Cin / 8) / 256, Cin <= 80 -> 12.7
 
 struct C3Args {
@@ -38,8 +37,11 @@ template <int ACT> __device__ __forceinline__ float c3_act(float v) {
 
 // NCH > 0: the K loop is fully unrolled (no back edge: the compiler can keep the next step's LDS reads in flight under this step's MFMAs; with a run-time
 // trip count it waited for every fragment right before its first use and the single wave per SIMD had nothing to hide that latency behind)
-template <int NBW, int ACT, int NCH>
+// MT = pixel groups (tile rows) per wave: the tile is 4*MT rows x 16 columns (16x16 at MT = 4; 8x16 at MT = 2, for panels of 5 cout blocks x 80 input
+// channels that leave no room for the 18x18 region)
+template <int NBW, int ACT, int NCH, int MT>
 __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
+  constexpr int TH = 4 * MT, RPX = (TH + 2) * C3_RW;            // tile rows, region pixels
   extern __shared__ __attribute__((aligned(16))) char c3_lds[];
   int* tab = (int*)c3_lds;                                          // [nchunks * 4] byte offset of piece p inside the region, relative to the pixel's row
   char* wl = c3_lds + (((size_t)a.nchunks * 16 + 15) & ~(size_t)15);
@@ -67,12 +69,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   for (int bw = 0; bw < NBW; ++bw) bias[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nb0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- staging of one tile's input region: item = (region pixel, 8-channel piece)
-  const int nitems = C3_RP * a.CP;
+  const int nitems = RPX * a.CP;
   uint4 stage[C3_MAXI];
   auto issue = [&](int t) {
     const int n = (int)fdiv((uint32_t)t, a.fd_tpi), rt = t - n * a.tiles_per_img;
     const int tyi = (int)fdiv((uint32_t)rt, a.fd_tx), txi = rt - tyi * a.tiles_x;
-    const int iy0 = tyi * C3_TW - 1, ix0 = txi * C3_TW - 1;
+    const int iy0 = tyi * TH - 1, ix0 = txi * C3_TW - 1;
 #pragma unroll
     for (int u = 0; u < C3_MAXI; ++u) {
       const int it = tid + u * 256;
@@ -95,9 +97,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   };
 
   const char* const wlane = wl + lane * 16;
-  int bbase[4];                                                      // region row address of this lane's pixel in the wave's four pixel groups
+  int bbase[MT];                                                     // region row address of this lane's pixel in the wave's pixel groups
 #pragma unroll
-  for (int m = 0; m < 4; ++m) bbase[m] = ((wave * 4 + m) * C3_RW + r) * a.XP;
+  for (int m = 0; m < MT; ++m) bbase[m] = ((wave * MT + m) * C3_RW + r) * a.XP;
 
   // every global load issued so far (bias, weights) is retired HERE: otherwise the compiler, unable to order them against the prefetches that are
   // pending at the loop's back edge, waits for vmcnt(0) - i.e. for the NEXT tile's prefetch - in front of the first MFMA of every tile
@@ -114,18 +116,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
     const int tn = t + wstep;
     if (tn < a.ntiles) issue(tn);                                    // in flight under this tile's MFMAs
 
-    f32x4 acc[NBW][4];
+    f32x4 acc[NBW][MT];
 #pragma unroll
     for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[bw][m] = bias[bw];
-    bf16x8 A[2][NBW], B[2][4];
+      for (int m = 0; m < MT; ++m) acc[bw][m] = bias[bw];
+    bf16x8 A[2][NBW], B[2][MT];
     auto load_frags = [&](int kc, int buf) {
       const int off = tab[kc * 4 + g];
 #pragma unroll
       for (int bw = 0; bw < NBW; ++bw) A[buf][bw] = *(const bf16x8*)(wlane + (size_t)(kc * NBW + bw) * 1024);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) B[buf][m] = *(const bf16x8*)(xs + bbase[m] + off);
+      for (int m = 0; m < MT; ++m) B[buf][m] = *(const bf16x8*)(xs + bbase[m] + off);
     };
     load_frags(0, 0);
     if (NCH > 0) {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 #pragma unroll
         for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc & 1][bw], B[kc & 1][m], acc[bw][m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc & 1][bw], B[kc & 1][m], acc[bw][m], 0, 0, 0);
       }
     } else {
       for (int kc = 0; kc < a.nchunks; kc += 2) {
@@ -143,13 +145,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 #pragma unroll
         for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][bw], B[0][m], acc[bw][m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][bw], B[0][m], acc[bw][m], 0, 0, 0);
         if (kc + 1 < a.nchunks) {
           if (kc + 2 < a.nchunks) load_frags(kc + 2, 0);
 #pragma unroll
           for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][bw], B[1][m], acc[bw][m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][bw], B[1][m], acc[bw][m], 0, 0, 0);
         }
       }
     }
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
       const int n = (int)fdiv((uint32_t)t, a.fd_tpi), rt = t - n * a.tiles_per_img;
       const int tyi = (int)fdiv((uint32_t)rt, a.fd_tx), txi = rt - tyi * a.tiles_x;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int oy = tyi * C3_TW + wave * 4 + m, ox = txi * C3_TW + r;
+      for (int m = 0; m < MT; ++m) {
+        const int oy = tyi * TH + wave * MT + m, ox = txi * C3_TW + r;
         const bool pin = oy < a.H && ox < a.W;
         const int po = n * a.ysn + oy * a.ysh + ox * a.ysw;
 #pragma unroll
@@ -198,40 +200,48 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   a.y = (char*)y->p; a.ysn = (int)(y->sn * 2); a.ysh = (int)(y->sh * 2); a.ysw = (int)(y->sw * 2); a.y_bytes = (uint32_t)exty;
   a.wpk = (const char*)packed_w; a.bias = bias;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = Cin; a.Cout = Cout; a.CP = CP; a.nchunks = nchunks; a.NTtot = NTtot; a.act = act;
-  a.tiles_x = cdiv(x->w, C3_TW);
-  a.tiles_per_img = a.tiles_x * cdiv(x->h, C3_TW);
-  a.ntiles = x->n * a.tiles_per_img;
   a.XP = Cin * 2 + 16;
-  if (C3_RP * CP > 256 * C3_MAXI) return false;
-  a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
   // every cout block in ONE workgroup (the input region is then staged once per tile); layers whose whole weight panel does not fit next to the
   // region stay on the igemm kernel: splitting the couts over workgroups re-reads the input per group and measured no faster
   const int NBW = NTtot;
-  if (NBW != 2 && NBW != 3 && NBW != 4 && NBW != 6) return false;
+  if (NBW != 2 && NBW != 3 && NBW != 4 && NBW != 5 && NBW != 6) return false;
+  if (NBW == 5 && mode < 2) return false;                   // 80 couts: only the 8x16-tile form fits and it measured slower than the igemm kernel (66.9 vs 55 us at 80 -> 80, 80x80, B = 32); MGDT_CONV3_LDS=2 forces it
   a.ncg = 1;
-  const size_t lds = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * 1024 + (size_t)C3_RP * a.XP;
-  if (lds > 160 * 1024) return false;
+  const size_t fixed = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * 1024;
+  int MT = 4;                                              // 16x16 tiles when the region fits next to the panel, else 8x16
+  if (fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP > 160 * 1024) MT = 2;
+  const size_t lds = fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP;
+  if (lds > 160 * 1024 || (NBW == 5 && MT != 2) || (NBW != 5 && MT != 4)) return false;      // instantiated: 5 blocks with 8x16 tiles, the others with 16x16
+  const int TH = 4 * MT;
+  a.tiles_x = cdiv(x->w, C3_TW);
+  a.tiles_per_img = a.tiles_x * cdiv(x->h, TH);
+  a.ntiles = x->n * a.tiles_per_img;
+  if ((TH + 2) * C3_RW * CP > 256 * C3_MAXI) return false;
+  a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
   int nwg = 256 / a.ncg * a.ncg;                                                                // one workgroup per CU, a multiple of the cout groups
   nwg = (int)std::min<long>(nwg, (long)a.ntiles * a.ncg);
   nwg = nwg / a.ncg * a.ncg;
   if (nwg < a.ncg) return false;
-#define C3_LAUNCH(NB, ACTV)                                                                                          \
+#define C3_LAUNCH(NB, ACTV, MTV)                                                                                          \
   {                                                                                                                  \
-    static bool attr = false, attr18 = false;                                                                        \
+    static bool attr = false, attr18 = false, attr23 = false;                                                                        \
     if (nchunks == 18) {                                                                                             \
-      if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
-      conv3x3_lds_kernel<NB, ACTV, 18><<<nwg, 256, lds, st>>>(a);                                                    \
+      if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 18, MTV><<<nwg, 256, lds, st>>>(a);                                                    \
+    } else if (nchunks == 23) {                                                                                      \
+      if (!attr23) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 23, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr23 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 23, MTV><<<nwg, 256, lds, st>>>(a);                                               \
     } else {                                                                                                         \
-      if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-      conv3x3_lds_kernel<NB, ACTV, 0><<<nwg, 256, lds, st>>>(a);                                                     \
+      if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 0, MTV><<<nwg, 256, lds, st>>>(a);                                                     \
     }                                                                                                                \
   }
-#define C3_ACT(NB) \
-  if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU) else C3_LAUNCH(NB, MGDT_ACT_NONE)
+#define C3_ACT(NB, MTV) \
+  if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU, MTV) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU, MTV) else C3_LAUNCH(NB, MGDT_ACT_NONE, MTV)
   static unsigned long long* dbgbuf = nullptr;
   if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);
   a.dbg = dbgbuf;
-  if (NBW == 6) { C3_ACT(6) } else if (NBW == 4) { C3_ACT(4) } else if (NBW == 3) { C3_ACT(3) } else { C3_ACT(2) }
+  if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
 #undef C3_ACT
 #undef C3_LAUNCH
   if (dbgbuf) {

@@ -1352,7 +1352,7 @@ def test_tood_model_trains_in_bf16_and_as_a_captured_step():
 
 C3_LDS_CASES = [  # (B, cin, cout, H, W, act, sliced views)
     (4, 64, 96, 80, 80, 'silu', False), (4, 80, 80, 80, 80, 'silu', False), (3, 32, 64, 72, 88, 'none', False), (2, 48, 48, 96, 100, 'relu', True),
-    (5, 64, 32, 64, 64, 'silu', True), (2, 72, 80, 120, 90, 'none', False),
+    (5, 64, 32, 64, 64, 'silu', True), (2, 72, 80, 120, 90, 'none', False), (3, 80, 80, 76, 84, 'relu', True),
 ]
 
 
