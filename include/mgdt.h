@@ -73,6 +73,11 @@ int mgdt_conv_pack_batch(const mgdt_pack_desc* descs, int n, mgdt_stream s);
 int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                     const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
                     const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s);
+/* One phase (py, px) = phase >> 1, phase & 1 of the data gradient of a stride-2 3x3 convolution: dx[:, 2i+py, 2j+px] as a stride-1 convolution of dy
+ * whose K holds only the taps that phase uses (packed by mgdt_conv_pack_dgrad(phase)); replaces the four 9-tap convolutions over mostly-zero weights.
+ * Reference: the autograd of the stride-2 nn.Conv2d layers (backbone rows 0, 1, 3, 5, 7 of models/v8/*.yaml). */
+int mgdt_conv2d_phase_fwd(const mgdt_view* x, const void* packed_w, const float* bias, int phase, const mgdt_view* r1, const mgdt_view* r2,
+                          const mgdt_view* y, int dtype, mgdt_stream s);
 
 /* ---- ConvNeXtV2 block MLP, hidden map kept on chip (nn/modules/convnextv2.py:62-77: pwconv1 -> GELU -> GRN -> pwconv2 -> + input).
  * t = LayerNorm output, res = the block input, y = res + pwconv2(GRN(gelu(pwconv1(t)))).  Two launches: GRN statistics, then

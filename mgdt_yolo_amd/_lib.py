@@ -40,6 +40,7 @@ PROTOTYPES = {
     'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
     'mgdt_conv_pack_batch': (_i, [_vp, _i, _vp]),
+    'mgdt_conv2d_phase_fwd': (_i, [VP, _vp, _vp, _i, VP, VP, VP, _i, _vp]),
     'mgdt_conv_wgrad_splits': (_i, [_i, _i, _i]),
     'mgdt_wgrad_final_batch': (_i, [_vp, _i, _vp]),
     'mgdt_conv_pack_dgrad': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

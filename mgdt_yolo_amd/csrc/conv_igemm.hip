@@ -51,6 +51,10 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
     int r = lane & 15, g = lane >> 4;
     int p = kc * 4 + g;
     int tap = p / CP, cp = p % CP;
+    if (dgrad >= 2) {                                  // compact K: list index -> the phase's tap (rows {1} / {1,2}, columns likewise)
+      const int nc_ = 1 + ((dgrad - 2) & 1), nr_ = 1 + ((dgrad - 2) >> 1);
+      tap = tap < nr_ * nc_ ? (1 + tap / nc_) * 3 + (1 + tap % nc_) : 99;
+    }
     int cin = cp * PE + j, cout = nb * 16 + r;
     float v = 0.f;
     if (tap < KS * KS && cin < Cin && cout < Cout) {
@@ -90,10 +94,19 @@ __global__ void fold_kernel(const float* cb, const float* g, const float* b, con
 // ------------------------------------------------------------------------------------------------ host side
 static inline int piece_elems(int dtype) { return dtype == MGDT_BF16 ? 8 : 4; }
 
-static void conv_geometry(int cin, int cout, int k, int dtype, int* CP, int* nchunks, int* NTtot) {
+// taps of phase (py, px) of a stride-2 3x3 data gradient (see pack_kernel): row taps {1} for py = 0, {1, 2} for py = 1, likewise the columns
+static inline int phase_ntaps(int mode) { return mode < 2 ? 9 : (1 + ((mode - 2) >> 1)) * (1 + ((mode - 2) & 1)); }
+static inline unsigned long long phase_taplist(int mode, int k) {
+  unsigned long long l = 0;
+  if (mode < 2) { for (int t = 0; t < k * k; ++t) l |= (unsigned long long)t << (4 * t); return l; }
+  const int nr = 1 + ((mode - 2) >> 1), nc = 1 + ((mode - 2) & 1);
+  for (int i = 0; i < nr * nc; ++i) l |= (unsigned long long)((1 + i / nc) * 3 + (1 + i % nc)) << (4 * i);
+  return l;
+}
+static void conv_geometry(int cin, int cout, int k, int dtype, int* CP, int* nchunks, int* NTtot, int ntaps = 0) {
   int pe = piece_elems(dtype);
   *CP = (cin + pe - 1) / pe;
-  int pieces = k * k * (*CP);
+  int pieces = (ntaps > 0 ? ntaps : k * k) * (*CP);
   *nchunks = (pieces + 3) / 4;
   *NTtot = (cout + 15) / 16;
 }
@@ -131,7 +144,7 @@ extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, in
   if (!w || !packed || !bias_out) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_dgrad: null pointer");
   if (phase < -1 || phase > 3 || (phase >= 0 && k != 3)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_pack_dgrad: phase %d (stride-2 phases need k = 3)", phase);
   int CP, nchunks, NTtot;
-  conv_geometry(cout, cin, k, dtype, &CP, &nchunks, &NTtot);       // the dgrad conv maps cout -> cin channels
+  conv_geometry(cout, cin, k, dtype, &CP, &nchunks, &NTtot, phase < 0 ? 0 : phase_ntaps(2 + phase));       // the dgrad conv maps cout -> cin channels; a phase keeps only its own taps
   hipStream_t st = (hipStream_t)s;
   float* scale = (float*)((char*)packed + (size_t)nchunks * NTtot * 1024);
   const int cpad = NTtot * 16;
@@ -182,6 +195,10 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
     int r = lane & 15, g = lane >> 4;
     int p = kc * 4 + g;
     int tap = p / CP, cp = p % CP;
+    if (dgrad >= 2) {                                  // compact K: list index -> the phase's tap (rows {1} / {1,2}, columns likewise)
+      const int nc_ = 1 + ((dgrad - 2) & 1), nr_ = 1 + ((dgrad - 2) >> 1);
+      tap = tap < nr_ * nc_ ? (1 + tap / nc_) * 3 + (1 + tap % nc_) : 99;
+    }
     int cin = cp * PE + j, cout = nb * 16 + r;
     float v = 0.f;
     if (tap < KS * KS && cin < Cin && cout < Cout) {
@@ -218,7 +235,7 @@ extern "C" int mgdt_conv_pack_batch(const mgdt_pack_desc* d, int n, mgdt_stream 
       if (e.mode < 0 || e.mode > 5 || (e.mode >= 2 && e.k != 3)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_pack_batch: descriptor %d mode %d", i, e.mode);
       PackJob& J = jobs.j[m++];
       const int gi = e.mode == 0 ? e.cin : e.cout, go = e.mode == 0 ? e.cout : e.cin;      // the data-gradient conv maps cout -> cin channels
-      conv_geometry(gi, go, e.k, dtype, &J.CP, &J.nchunks, &J.NTtot);
+      conv_geometry(gi, go, e.k, dtype, &J.CP, &J.nchunks, &J.NTtot, e.mode >= 2 ? phase_ntaps(e.mode) : 0);
       J.w = e.w; J.Cin = gi; J.Cout = go; J.KS = e.k; J.dgrad = e.mode; J.out = e.packed;
       J.fa = e.mode == 0 ? FoldArgs{e.conv_bias, e.bn_gamma, e.bn_beta, e.bn_mean, e.bn_var, e.bn_eps, go, J.NTtot * 16, e.bias_out}
                          : FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, go, J.NTtot * 16, e.bias_out};
@@ -244,9 +261,24 @@ static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, int
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: no kernel for NT=%d MT=%d", NT, MT);
 }
 
+static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
+                           const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
+                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s);
 extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                                const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
                                const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s) {
+  return conv2d_fwd_impl(x, x2, in_scale, in_shift, packed_w, bias, k, stride, act, r1, r2, y, dtype, 0, s);
+}
+// The phase convolutions of a stride-2 3x3 data gradient: panels packed by mgdt_conv_pack_dgrad(phase = 0..3) hold only the 1, 2 or 4 taps the
+// phase uses (K = taps * channels instead of 9 * channels); `phase` selects the matching tap list.  k = 3, stride 1.
+extern "C" int mgdt_conv2d_phase_fwd(const mgdt_view* x, const void* packed_w, const float* bias, int phase, const mgdt_view* r1, const mgdt_view* r2,
+                                     const mgdt_view* y, int dtype, mgdt_stream s) {
+  if (phase < 0 || phase > 3) MGDT_FAIL(MGDT_BAD_ARG, "conv2d_phase: phase %d", phase);
+  return conv2d_fwd_impl(x, nullptr, nullptr, nullptr, packed_w, bias, 3, 1, MGDT_ACT_NONE, r1, r2, y, dtype, 2 + phase, s);
+}
+static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
+                           const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
+                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y) || !packed_w || !bias) MGDT_FAIL(MGDT_BAD_ARG, "conv2d: null/empty view or weights");
   if (dtype != MGDT_F32 && dtype != MGDT_BF16) MGDT_FAIL(MGDT_BAD_DTYPE, "conv2d: dtype %d", dtype);
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: k=%d stride=%d unsupported", k, stride);
@@ -288,13 +320,15 @@ extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const fl
   a.wpk = (const char*)packed_w; a.bias = bias;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Ho = Ho; a.Wo = Wo; a.Cout = y->c;
   a.KS = k; a.stride = stride; a.pad = pad; a.act = act;
-  conv_geometry(a.Cin, a.Cout, k, dtype, &a.CP, &a.nchunks, &a.NTtot);
+  a.ntaps = tapmode >= 2 ? phase_ntaps(tapmode) : k * k;
+  a.taplist = phase_taplist(tapmode, k);
+  conv_geometry(a.Cin, a.Cout, k, dtype, &a.CP, &a.nchunks, &a.NTtot, tapmode >= 2 ? a.ntaps : 0);
   long M = (long)a.N * Ho * Wo;
   if (M > 0x7fffffffL - (1 << 20)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: problem too large");
   a.M = (int)M; a.HoWo = Ho * Wo;
   a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
   // plain 3x3 stride-1 bf16 layers with 32-80 input channels on large maps: the LDS-staged kernel (conv3x3_lds.hip)
-  if (dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
+  if (tapmode == 0 && dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
       mgdt_conv3x3_lds_launch(x, y, packed_w, bias, act, a.CP, a.nchunks, a.NTtot, (hipStream_t)s)) {
     MGDT_CHECK_LAUNCH("conv2d(3x3 lds)");
     return MGDT_OK;

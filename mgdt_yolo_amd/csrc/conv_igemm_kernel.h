@@ -24,6 +24,7 @@ struct ConvArgs {   // all strides / offsets in BYTES and < 2 GiB (host-checked)
   int M, HoWo, numTiles, T8, seg_chunks, nseg, tab_bytes;
   FastDiv fd_howo, fd_wo;
   uint32_t x_bytes, x2_bytes, y_bytes, r1_bytes, r2_bytes;   // addressable extents of the views (buffer descriptor ranges)
+  int ntaps; unsigned long long taplist;                     // K enumerates these taps only (4 bits each; all KS*KS by default): the phase convs of a stride-2 data gradient use 1, 2 or 4 of the 9
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   const int ssh = a.stride >> 1;       // stride is 1 or 2 (host-checked): multiply by shifting
 
   for (int p = tid; p < nchp * 4; p += nthr) {   // table padded to nchp chunks: padding pieces carry tap 31 (never valid)
-    int tap = p / a.CP, cp = p % a.CP;
+    const int li = p / a.CP, cp = p % a.CP;
     uint4 e = make_uint4(0u, 31u, 0u, 0u);
-    if (tap < a.KS * a.KS) {
+    if (li < a.ntaps) {
+      const int tap = (int)((a.taplist >> (4 * li)) & 15ull);
       const int dy = tap / a.KS, dx = tap % a.KS;
       e = make_uint4((uint32_t)(dy * a.xsh + dx * a.xsw + cp * PE * SZ), (uint32_t)tap, (uint32_t)(dy * a.x2sh + dx * a.x2sw + cp * PE * SZ), (uint32_t)(cp * PE));
     }

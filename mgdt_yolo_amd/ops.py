@@ -812,8 +812,14 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False, r2=None):
             pks = _DGRAD_PK[(weight.data_ptr(), 2)] = [_PackedDgrad(weight, 3, dy.dtype, key, phase=ph) for ph in range(4)]
         for ph in range(4):
             sub = dx[:, :, ph >> 1::2, ph & 1::2]
-            conv2d(dy, pks[ph], 1, ACT_NONE, out=sub, r1=None if r1_ is None else r1_[:, :, ph >> 1::2, ph & 1::2],
-                   r2=None if r2_ is None else r2_[:, :, ph >> 1::2, ph & 1::2])
+            ra = None if r1_ is None else r1_[:, :, ph >> 1::2, ph & 1::2]
+            rb = None if r2_ is None else r2_[:, :, ph >> 1::2, ph & 1::2]
+            _same(dy, sub, ra, rb)
+            if _PROF is not None:
+                ntap = (1 + (ph >> 1)) * (1 + (ph & 1))
+                _META['conv2d_fwd'] = dict(shape=(dy.shape[0], cout, dy.shape[2], dy.shape[3], cin, 3, 1), flops=2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cin * cout * ntap,
+                                           bytes=float(dy.numel() * dy.element_size() + sub.numel() * sub.element_size() + pks[ph].w.numel()))
+            _launch('conv2d_fwd', 'mgdt_conv2d_phase_fwd', vp(dy), ptr(pks[ph].w), ptr(pks[ph].bias), ph, vp(ra), vp(rb), vp(sub), dtype_code(dy.dtype), stream())
         return dx
     _same(dy, dx)
     _launch('conv_dgrad', 'mgdt_conv_dgrad', vp(dy), ptr(weight), k, stride, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
