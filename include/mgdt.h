@@ -206,7 +206,10 @@ int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const mgdt_view*
 int mgdt_adaptive_avgpool_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
 int mgdt_bilinear_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s); /* align_corners=False */
 int mgdt_nearest_fwd(const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
-int mgdt_copy_fwd(const mgdt_view* x, int x_dtype, const mgdt_view* y, int y_dtype, mgdt_stream s); /* cat / layout / cast */
+int mgdt_copy_fwd(const mgdt_view* x, int x_dtype, const mgdt_view* y, int y_dtype, mgdt_stream s);
+/* The 1-3 channel image (any strides; MGDT_U8 is divided by 255: detect/train.py:64) as a 4-channel NHWC map whose remaining channels are zero - the input the
+ * stem's weight-gradient kernel reads.  Writes all four channels of y. */
+int mgdt_image_pad4_fwd(const mgdt_view* x, int x_dtype, const mgdt_view* y, int y_dtype, mgdt_stream s); /* cat / layout / cast */
 
 /* ---- ConvNeXtV2 block pieces (nn/modules/convnextv2.py:48-77, nn/modules/utils.py:145-182) -------------
  * dwln: y = LayerNorm_c(dwconv7x7(x) + b) * ln_w + ln_b   (eps 1e-6), dw_w is [49][c] fp32.

@@ -54,6 +54,7 @@ PROTOTYPES = {
     'mgdt_bilinear_fwd': (_i, [VP, VP, _i, _vp]),
     'mgdt_nearest_fwd': (_i, [VP, VP, _i, _vp]),
     'mgdt_copy_fwd': (_i, [VP, _i, VP, _i, _vp]),
+    'mgdt_image_pad4_fwd': (_i, [VP, _i, VP, _i, _vp]),
     'mgdt_dwconv7_ln_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, VP, _i, _vp]),
     'mgdt_cnx_mlp_packed_bytes': (_sz, [_i, _i]),
     'mgdt_cnx_mlp_pack': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),

@@ -99,6 +99,45 @@ __global__ void copy_vec_kernel(const TX* __restrict__ x, long xsn, long xsh, lo
   }
 }
 
+// The 3-channel image (any layout: NCHW planes as the dataloader hands it; uint8 is divided by 255 as detect/train.py:64 does) as a 4-channel NHWC map with
+// a zero 4th channel: what the weight-gradient kernels of the stem read.  One thread per pixel: three coalesced plane reads, one 8 / 16-byte store.
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void image_pad4_kernel(const TX* __restrict__ x, long xsn, long xsh, long xsw, long xsc, TY* __restrict__ y, long ysn, long ysh,
+                                                         long ysw, int N, int H, int W, int C) {
+  const long total = (long)N * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    long t = i / W;
+    const int h = (int)(t % H);
+    const long n = t / H;
+    const TX* xp = x + n * xsn + h * xsh + w * xsw;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < C) v[c] = std::is_same<TX, uint8_t>::value ? (float)xp[c * xsc] / 255.f : (float)xp[c * xsc];
+    store4<TY>(y + n * ysn + h * ysh + w * ysw, v);
+  }
+}
+extern "C" int mgdt_image_pad4_fwd(const mgdt_view* x, int xdt, const mgdt_view* y, int ydt, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "image_pad4: null/empty view");
+  if (x->c < 1 || x->c > 3 || y->c != 4 || x->n != y->n || x->h != y->h || x->w != y->w || y->sc != 1 || y->sw % 4 || y->sh % 4 || y->sn % 4 ||
+      (uintptr_t)y->p % (4 * dtype_size(ydt)))
+    MGDT_FAIL(MGDT_BAD_SHAPE, "image_pad4: x with 1-3 channels, y a 4-channel NHWC view of the same size");
+  const long total = (long)x->n * x->h * x->w;
+  const int g = (int)std::min<long>((total + 255) / 256, 16384);
+  hipStream_t st = (hipStream_t)s;
+#define LP(TX, TY) image_pad4_kernel<TX, TY><<<g, 256, 0, st>>>((const TX*)x->p, x->sn, x->sh, x->sw, x->sc, (TY*)y->p, y->sn, y->sh, y->sw, x->n, x->h, x->w, x->c)
+  if (xdt == MGDT_U8 && ydt == MGDT_BF16) LP(uint8_t, bf16);
+  else if (xdt == MGDT_U8 && ydt == MGDT_F32) LP(uint8_t, float);
+  else if (xdt == MGDT_F32 && ydt == MGDT_F32) LP(float, float);
+  else if (xdt == MGDT_F32 && ydt == MGDT_BF16) LP(float, bf16);
+  else if (xdt == MGDT_BF16 && ydt == MGDT_BF16) LP(bf16, bf16);
+  else MGDT_FAIL(MGDT_BAD_DTYPE, "image_pad4: dtypes %d -> %d", xdt, ydt);
+#undef LP
+  MGDT_CHECK_LAUNCH("image_pad4_fwd");
+  return MGDT_OK;
+}
+
 extern "C" int mgdt_copy_fwd(const mgdt_view* x, int xdt, const mgdt_view* y, int ydt, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y)) MGDT_FAIL(MGDT_BAD_ARG, "copy: null/empty view");
   if (x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c) MGDT_FAIL(MGDT_BAD_SHAPE, "copy: shape mismatch");

@@ -2,7 +2,7 @@
 // spr_module.py, convnextv2.py:48-77, utils.py:145-182).  First-cut, deterministic (fixed-order reductions), NHWC.
 #include "common.h"
 
-#define NC_SPLITS 16
+#define NC_SPLITS 64
 
 // channel-vectorised forms (train_vec.hip); false -> run the scalar kernel
 bool mgdt_v4_ew_binary(const mgdt_view* a, const mgdt_view* b, const mgdt_view* o, int mode, int dtype, hipStream_t st);

@@ -832,8 +832,8 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         # the 3-channel image (NCHW): one strided copy into a 4-channel NHWC buffer (4th channel zero) puts the stem on the tiled NHWC kernel;
         # the generic kernel would scan every pixel once per weight element
         b, c, h, w = x.shape
-        x4 = new_act(b, 4, h, w, dy.dtype, x.device).zero_()           # in dy's dtype; a uint8 image is divided by 255 by the copy (detect/train.py:64)
-        copy(x, x4[:, :c])
+        x4 = new_act(b, 4, h, w, dy.dtype, x.device)                   # in dy's dtype; a uint8 image is divided by 255 on the way (detect/train.py:64)
+        _launch('copy_fwd', 'mgdt_image_pad4_fwd', vp(x), U8 if x.dtype == torch.uint8 else dtype_code(x.dtype), vp(x4), dtype_code(x4.dtype), stream())
         dw4 = torch.empty((dw.shape[0], 4, k, k), dtype=torch.float32, device=x.device)
         conv_wgrad(x4, dy, k, stride, dw4, dbias=dbias)
         flush_wgrad()                                  # dw4 is read right below
