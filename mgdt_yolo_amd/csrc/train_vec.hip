@@ -258,64 +258,64 @@ bool mgdt_v4_nc_reduce_partial(const mgdt_view* a, const mgdt_view* b, float* pa
 
 // MaxPool2d(5,1,2) backward with the image's map in LDS: workgroup = (image, block of CB channels); pass 1 finds every window's argmax
 // (ATen's scan order: first maximum in (ky,kx) order, a NaN replaces what was found before it), pass 2 gathers gy over the windows whose
-// argmax is the pixel, in (oy, ox) order.  50 LDS reads per element instead of 625 cached global loads.
+// argmax is the pixel, in (oy, ox) order.  All three LDS maps carry a 2-pixel halo (x: -inf, argmax: a value no pixel has, gy: 0), so the 25-tap
+// loops have no bounds tests: their LDS reads are independent and pipeline (with the tests every read waited for the previous compare: 107 us).
 template <typename T>
 __global__ __launch_bounds__(256) void v4_maxpool5_bwd_kernel(const mgdt_view x, const mgdt_view gy, float* __restrict__ gx_f32, int CB) {
   extern __shared__ float lds[];
   const int H = x.h, W = x.w, HW = H * W, n = blockIdx.x, c0 = blockIdx.y * CB;
-  float* xs = lds;                                      // [HW][CB]
-  float* gs = lds + (size_t)HW * CB;                    // [HW][CB] gy
-  unsigned short* am = (unsigned short*)(gs + (size_t)HW * CB);   // [HW][CB] argmax pixel index
+  const int HP = H + 4, WP = W + 4, PP = HP * WP;
+  float* xs = lds;                                      // [PP][CB]
+  float* gs = lds + (size_t)PP * CB;                    // [PP][CB] gy
+  unsigned short* am = (unsigned short*)(gs + (size_t)PP * CB);   // [PP][CB] argmax = padded index of the window's maximum
   const int QB = CB >> 2;
-  for (int i = threadIdx.x; i < HW * QB; i += 256) {
-    const int p = i / QB, q = i - p * QB;
-    const int yy = p / W, xx = p - yy * W;
-    const bool in = c0 + 4 * q < x.c;
-    *(f32x4*)(xs + (size_t)p * CB + 4 * q) = in ? load4<T>(P4(const T, x, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    *(f32x4*)(gs + (size_t)p * CB + 4 * q) = in ? load4<T>(P4(const T, gy, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < PP * QB; i += 256) {
+    const int pp = i / QB, q = i - pp * QB;
+    const int yy = pp / WP - 2, xx = pp % WP - 2;
+    const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && c0 + 4 * q < x.c;
+    *(f32x4*)(xs + (size_t)pp * CB + 4 * q) = in ? load4<T>(P4(const T, x, (long)n, yy, xx, c0 + 4 * q)) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    *(f32x4*)(gs + (size_t)pp * CB + 4 * q) = in ? load4<T>(P4(const T, gy, (long)n, yy, xx, c0 + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  for (int i = threadIdx.x; i < PP * CB; i += 256) am[i] = 0xFFFFu;
   __syncthreads();
   for (int i = threadIdx.x; i < HW * CB; i += 256) {
     const int p = i / CB, c = i - p * CB;
     const int oy = p / W, ox = p - oy * W;
+    const int base = (oy * WP + ox) * CB + c;            // padded (oy, ox) = window's top-left corner
+    float v[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) v[t] = xs[base + ((t / 5) * WP + (t % 5)) * CB];
     float best = -INFINITY;
-    int bi = p;
-    for (int dy = -2; dy <= 2; ++dy) {
-      const int yy = oy + dy;
-      if ((unsigned)yy >= (unsigned)H) continue;
-      for (int dx = -2; dx <= 2; ++dx) {
-        const int xx = ox + dx;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        const float v = xs[(size_t)(yy * W + xx) * CB + c];
-        if (v > best || isnan(v)) { best = v; bi = yy * W + xx; }
-      }
-    }
-    am[(size_t)p * CB + c] = (unsigned short)bi;
+    int bt = 12;                                         // a window whose every value is -inf (cannot happen for in-image data) keeps its centre
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+      if (v[t] > best || isnan(v[t])) { best = v[t]; bt = t; }      // halo values (-inf) never win: `>` is strict
+    am[((oy + 2) * WP + ox + 2) * CB + c] = (unsigned short)((oy + bt / 5) * WP + ox + bt % 5);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < HW * CB; i += 256) {
     const int p = i / CB, c = i - p * CB;
     if (c0 + c >= x.c) continue;
     const int h = p / W, w = p - h * W;
+    const int me = (h + 2) * WP + w + 2;
+    const int base = (h * WP + w) * CB + c;              // padded (h, w): the first window (oy = h - 2, ox = w - 2) that contains the pixel
     float acc = 0.f;
-    for (int oy = h - 2; oy <= h + 2; ++oy) {
-      if ((unsigned)oy >= (unsigned)H) continue;
-      for (int ox = w - 2; ox <= w + 2; ++ox) {
-        if ((unsigned)ox >= (unsigned)W) continue;
-        if (am[(size_t)(oy * W + ox) * CB + c] == p) acc += gs[(size_t)(oy * W + ox) * CB + c];
-      }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+      const int o = base + ((t / 5) * WP + (t % 5)) * CB;
+      acc += am[o] == me ? gs[o] : 0.f;
     }
     gx_f32[((long)n * HW + p) * x.c + c0 + c] = acc;
   }
 }
 bool mgdt_v4_maxpool5_bwd(const mgdt_view* x, const mgdt_view* gy, float* gx_f32, int dtype, hipStream_t st) {
   if (!v4_ok(x, dtype) || !v4_ok(gy, dtype)) return false;
-  const long HW = (long)x->h * x->w;
-  if (HW > 65535) return false;
+  const long PP = (long)(x->h + 4) * (x->w + 4);
+  if (PP > 65534) return false;
   int CB = 16;
-  while (CB > 4 && HW * CB * 10 > 64 * 1024) CB >>= 1;      // x (4 B) + gy (4 B) + argmax (2 B) per element within the default 64 KB
-  if (HW * CB * 10 > 64 * 1024) return false;
-  const size_t lds = (size_t)HW * CB * 10;
+  while (CB > 4 && PP * CB * 10 > 64 * 1024) CB >>= 1;      // x (4 B) + gy (4 B) + argmax (2 B) per padded element within the default 64 KB
+  if (PP * CB * 10 > 64 * 1024) return false;
+  const size_t lds = (size_t)PP * CB * 10;
   MGDT_DISPATCH_DTYPE(dtype, (v4_maxpool5_bwd_kernel<T><<<dim3(x->n, (x->c + CB - 1) / CB), 256, lds, st>>>(*x, *gy, gx_f32, CB)));
   return true;
 }
