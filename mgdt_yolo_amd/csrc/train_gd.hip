@@ -570,18 +570,22 @@ __global__ __launch_bounds__(256) void dwconv7_dgrad_vec_kernel(const mgdt_view 
     t /= dx.w;
     const int h = (int)(t % dx.h);
     const long n = t / dx.h;
+    // branch-free taps: out-of-range positions read a clamped (valid) address and are multiplied by 0 - with `continue` around the loads every load
+    // waited for the previous bounds test and the 49 taps ran as one dependent chain
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       const int oy = h + 3 - ky;
-      if ((unsigned)oy >= (unsigned)du.h) continue;
+      const bool vy = (unsigned)oy < (unsigned)du.h;
+      const int oyc = min(max(oy, 0), du.h - 1);
 #pragma unroll
       for (int kx = 0; kx < 7; ++kx) {
         const int ox = w + 3 - kx;
-        if ((unsigned)ox >= (unsigned)du.w) continue;
-        const f32x4 g = load4<T>(AT4(const T, du, n, oy, ox, 4 * q));
+        const float m = (vy && (unsigned)ox < (unsigned)du.w) ? 1.f : 0.f;
+        const int oxc = min(max(ox, 0), du.w - 1);
+        const f32x4 g = load4<T>(AT4(const T, du, n, oyc, oxc, 4 * q));
         const f32x4 wv = *(const f32x4*)(w49c + (ky * 7 + kx) * dx.c + 4 * q);
-        acc += g * wv;
+        acc += g * wv * m;
       }
     }
     if (accumulate) acc += load4<T>(AT4(const T, dx, n, h, w, 4 * q));
@@ -609,11 +613,14 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_vec_kernel(const mgdt_view 
       const f32x4 g = load4<T>(AT4(const T, du, n, oy, ox, 4 * q));
       acc[7] += g;
       const int iy = oy + ky - 3;
-      if ((unsigned)iy >= (unsigned)x.h) continue;
+      const bool vy = (unsigned)iy < (unsigned)x.h;
+      const int iyc = min(max(iy, 0), x.h - 1);
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
+      for (int kx = 0; kx < 7; ++kx) {                   // branch-free: clamped address, zero weight outside the image
         const int ix = ox + kx - 3;
-        if ((unsigned)ix < (unsigned)x.w) acc[kx] += g * load4<T>(AT4(const T, x, n, iy, ix, 4 * q));
+        const float m = (vy && (unsigned)ix < (unsigned)x.w) ? 1.f : 0.f;
+        const int ixc = min(max(ix, 0), x.w - 1);
+        acc[kx] += g * load4<T>(AT4(const T, x, n, iyc, ixc, 4 * q)) * m;
       }
     }
   __shared__ float red[8][4][256];
