@@ -82,8 +82,18 @@ bool mgdt_v4_channel_affine(const mgdt_view* x, const float* scale, const float*
 
 template <typename T>
 __global__ __launch_bounds__(256) void v4_avgpool_bwd_kernel(const mgdt_view gy, const mgdt_view gx, int accumulate) {
+  const int fy = (gx.h % gy.h == 0 && gx.w % gy.w == 0) ? gx.h / gy.h : 0, fx = fy ? gx.w / gy.w : 0;
   FOR_QUADS(gx) {
     DECODE_Q(i, gx, n, h, w, c)
+    if (fy > 0) {                                        // integer pooling factors: the pixel lies in exactly one bin of fy x fx pixels
+      f32x4 acc = load4<T>(P4(const T, gy, n, h / fy, w / fx, c));
+      const float cnt = (float)(fy * fx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = acc[j] / cnt;
+      if (accumulate) acc += load4<T>(P4(const T, gx, n, h, w, c));
+      store4<T>(P4(T, gx, n, h, w, c), acc);
+      continue;
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int oy_lo = max(0, (int)(((long)h * gy.h) / gx.h) - 1), oy_hi = min(gy.h - 1, (int)(((long)(h + 1) * gy.h) / gx.h) + 1);
     const int ox_lo = max(0, (int)(((long)w * gy.w) / gx.w) - 1), ox_hi = min(gy.w - 1, (int)(((long)(w + 1) * gy.w) / gx.w) + 1);
