@@ -466,47 +466,47 @@ extern "C" int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, co
 }
 
 // ------------------------------------------------------------------------------------------------ SPPF pools
-// One workgroup = one image x 8 channels: the whole HxW plane (20x20 at 640^2) sits in LDS as fp32 and MaxPool2d(5,1,2)
-// is applied three times as separable row / column 5-tap max passes (-inf padding), writing y1, y2, y3 after each.
+// One workgroup = one image x 8 channels: the whole HxW plane (20x20 at 640^2) sits in LDS as fp32 with a 2-pixel -inf halo and MaxPool2d(5,1,2)
+// is applied three times as separable row / column 5-tap max passes, writing y1, y2, y3 after each.  The halo makes the taps unconditional: with
+// bounds tests around the LDS reads every read waited for the previous compare (32 us for a 3 MB map).
 template <typename T, int SPPF_CG>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y1, long s1n,
                                                         long s1h, long s1w, T* __restrict__ y2, long s2n, long s2h, long s2w,
                                                         T* __restrict__ y3, long s3n, long s3h, long s3w, int H, int W) {
   extern __shared__ float sm[];
-  const int n = blockIdx.x, c0 = blockIdx.y * SPPF_CG, HW = H * W;
-  float* A = sm;                  // [HW][SPPF_CG]
-  float* Bf = sm + HW * SPPF_CG;
+  const int n = blockIdx.x, c0 = blockIdx.y * SPPF_CG, HW = H * W, WP = W + 4, PP = (H + 4) * WP;
+  float* A = sm;                  // [PP][SPPF_CG]
+  float* Bf = sm + PP * SPPF_CG;
   constexpr int QN = SPPF_CG / 4;
-  for (int i = threadIdx.x; i < HW * QN; i += 256) {   // 4 channels per lane
-    int p = i / QN, qq = (i % QN) * 4;
-    f32x4 v = load4<T>(x + n * xsn + (p / W) * xsh + (p % W) * xsw + c0 + qq);
-    *(f32x4*)(A + p * SPPF_CG + qq) = v;
+  const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < PP * QN; i += 256) {   // 4 channels per lane
+    const int pp = i / QN, qq = (i % QN) * 4;
+    const int hh = pp / WP - 2, ww = pp % WP - 2;
+    const bool in = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+    *(f32x4*)(A + pp * SPPF_CG + qq) = in ? load4<T>(x + n * xsn + hh * xsh + ww * xsw + c0 + qq) : ninf;
+    *(f32x4*)(Bf + pp * SPPF_CG + qq) = ninf;
   }
   __syncthreads();
   T* outs[3] = {y1, y2, y3};
   const long on[3] = {s1n, s2n, s3n}, oh[3] = {s1h, s2h, s3h}, ow[3] = {s1w, s2w, s3w};
   for (int pass = 0; pass < 3; ++pass) {
     for (int i = threadIdx.x; i < HW * SPPF_CG; i += 256) {   // rows: A -> Bf
-      int c = i % SPPF_CG, p = i / SPPF_CG, w = p % W, rowb = p - w;
-      float m = A[i];
-#pragma unroll
-      for (int d = -2; d <= 2; ++d)
-        if (d != 0 && (unsigned)(w + d) < (unsigned)W) m = fmaxf(m, A[(rowb + w + d) * SPPF_CG + c]);
-      Bf[i] = m;
+      const int c = i % SPPF_CG, p = i / SPPF_CG, h = p / W, w = p - h * W;
+      const int o = ((h + 2) * WP + w + 2) * SPPF_CG + c;
+      const float a0 = A[o - 2 * SPPF_CG], a1 = A[o - SPPF_CG], a2 = A[o], a3 = A[o + SPPF_CG], a4 = A[o + 2 * SPPF_CG];
+      Bf[o] = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), a4);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < HW * SPPF_CG; i += 256) {   // columns: Bf -> A
-      int c = i % SPPF_CG, p = i / SPPF_CG, h = p / W, w = p - h * W;
-      float m = Bf[i];
-#pragma unroll
-      for (int d = -2; d <= 2; ++d)
-        if (d != 0 && (unsigned)(h + d) < (unsigned)H) m = fmaxf(m, Bf[((h + d) * W + w) * SPPF_CG + c]);
-      A[i] = m;
+      const int c = i % SPPF_CG, p = i / SPPF_CG, h = p / W, w = p - h * W;
+      const int o = ((h + 2) * WP + w + 2) * SPPF_CG + c, rs = WP * SPPF_CG;
+      const float b0 = Bf[o - 2 * rs], b1 = Bf[o - rs], b2 = Bf[o], b3 = Bf[o + rs], b4 = Bf[o + 2 * rs];
+      A[o] = fmaxf(fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)), b4);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < HW * QN; i += 256) {
-      int p = i / QN, qq = (i % QN) * 4;
-      store4<T>(outs[pass] + n * on[pass] + (p / W) * oh[pass] + (p % W) * ow[pass] + c0 + qq, *(const f32x4*)(A + p * SPPF_CG + qq));
+      const int p = i / QN, qq = (i % QN) * 4, h = p / W, w = p - h * W;
+      store4<T>(outs[pass] + n * on[pass] + h * oh[pass] + w * ow[pass] + c0 + qq, *(const f32x4*)(A + ((h + 2) * WP + w + 2) * SPPF_CG + qq));
     }
   }
 }
@@ -517,9 +517,9 @@ extern "C" int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const
   for (const mgdt_view* v : {x, y1, y2, y3})
     if (!vec4_ok(v, dtype) || v->n != x->n || v->h != x->h || v->w != x->w || v->c != x->c)
       MGDT_FAIL(MGDT_BAD_SHAPE, "sppf_pool: views must be matching NHWC, c%%4==0");
-  const long hw = (long)x->h * x->w;
-  const int cg = (x->c % 8 == 0 && hw * 8 * 2 * 4 <= 64 * 1024) ? 8 : 4;          // channels per workgroup so the plane fits 64 KiB of LDS
-  size_t lds = (size_t)hw * cg * 2 * sizeof(float);
+  const long pp = (long)(x->h + 4) * (x->w + 4);                                  // plane with its 2-pixel halo
+  const int cg = (x->c % 8 == 0 && pp * 8 * 2 * 4 <= 64 * 1024) ? 8 : 4;          // channels per workgroup so the planes fit 64 KiB of LDS
+  size_t lds = (size_t)pp * cg * 2 * sizeof(float);
   if (lds > 64 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "sppf_pool: the %dx%d map does not fit the LDS plane kernel (h*w <= 2048)", x->h, x->w);
   dim3 grid(x->n, x->c / cg);
 #define SPPF_L(CG) MGDT_DISPATCH_DTYPE(dtype, (sppf_pool_kernel<T, CG><<<grid, 256, lds, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, (T*)y1->p, y1->sn, y1->sh, y1->sw, \
