@@ -1388,3 +1388,92 @@ def test_conv3x3_lds_staged_kernel(case):
     assert err < 1.5 * 2 ** -8 * ref.abs().max().item(), (err, ref.abs().max().item())
     if view:
         assert float(y._base[:, :8].abs().max()) == 0.0 and float(y._base[:, 8 + co:].abs().max()) == 0.0      # neighbouring channels untouched
+
+
+@pytest.mark.gpu
+def test_batched_repack_equals_individual_packs():
+    """ops.repack_all() (mgdt_conv_pack_batch: every live panel in a few launches after an optimizer step) writes exactly the bytes the
+    one-at-a-time packs write: forward panels with and without BN fold, stride-1 data-gradient panels, the four stride-2 phase panels; and a
+    panel built from a derived copy (not live parameter storage) is never refreshed in place."""
+    from mgdt_yolo_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    store = torch.randn(200000, generator=gen).to(DEV)
+    ops.LIVE_STORAGES.add(store.untyped_storage().data_ptr())
+    try:
+        off = [0]
+
+        def take(*shape):
+            n = int(np.prod(shape))
+            t = store[off[0]:off[0] + n].view(*shape)
+            off[0] += (n + 3) // 4 * 4
+            return t
+        w1, w2, w3 = take(48, 32, 3, 3), take(24, 64, 1, 1), take(64, 32, 3, 3)
+        bn = (take(48).abs_().add_(0.5), take(48), take(48), take(48).abs_().add_(0.5), 1e-3)            # views of the live storage, adjusted in place
+        cb = take(24)
+        packs = [ops.PackedConv(w1, None, bn, 3, torch.bfloat16), ops.PackedConv(w2, cb, None, 1, torch.bfloat16), ops.PackedConv(w1, None, None, 3, torch.float32),
+                 ops._PackedDgrad(w3, 3, torch.bfloat16, ('k',)), ops._PackedDgrad(w2, 1, torch.float32, ('k',))]
+        packs += [ops._PackedDgrad(w3, 3, torch.bfloat16, ('k',), phase=ph) for ph in range(4)]
+        copy_pack = ops.PackedConv(torch.cat([w2, w2]), None, None, 1, torch.bfloat16)             # derived copy: must not be registered
+        assert all(getattr(p, 'epoch', None) == ops.PARAM_EPOCH[0] for p in packs) and getattr(copy_pack, 'epoch', None) is None
+        store.mul_(1.5).add_(0.01)                                                                 # "optimizer step" behind torch's back
+        bn[3].abs_()                                                                               # the variance stays positive
+        ops.PARAM_EPOCH[0] += 1
+        n = ops.repack_all()
+        assert n >= len(packs)
+        fresh = [ops.PackedConv(w1, None, bn, 3, torch.bfloat16), ops.PackedConv(w2, cb, None, 1, torch.bfloat16), ops.PackedConv(w1, None, None, 3, torch.float32),
+                 ops._PackedDgrad(w3, 3, torch.bfloat16, ('k',)), ops._PackedDgrad(w2, 1, torch.float32, ('k',))]
+        fresh += [ops._PackedDgrad(w3, 3, torch.bfloat16, ('k',), phase=ph) for ph in range(4)]
+        taps = [9, 1, 9, 9, 1, 1, 2, 2, 4]                       # K taps of each panel (the phase panels keep 1 / 2 / 2 / 4 of the 9)
+        for a, b, t in zip(packs, fresh, taps):
+            assert ops.pack_is_current(a)
+            pe = 8 if a.dtype == torch.bfloat16 else 4
+            nbytes = -(-t * -(-a.cin // pe) // 4) * -(-a.cout // 16) * 1024                        # the panel itself (the buffers carry scratch behind it)
+            assert torch.equal(a.w[:nbytes], b.w[:nbytes]) and torch.equal(a.bias, b.bias)
+    finally:
+        ops.LIVE_STORAGES.discard(store.untyped_storage().data_ptr())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_deferred_weight_gradient_sums_equal_the_immediate_form(dtype):
+    """Inside ops.defer_wgrad() a convolution leaves its per-split partial sums in its workspace and one mgdt_wgrad_final_batch launch finishes all
+    of them: bit-identical to the immediate form (same fixed summation order); an accumulating gradient flushes the pending ones first."""
+    from mgdt_yolo_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    cases = [(mk(2, 16, 24, 24), mk(2, 32, 24, 24), 3, 1), (mk(2, 64, 12, 12), mk(2, 24, 12, 12), 1, 1), (mk(2, 8, 32, 32), mk(2, 16, 16, 16), 3, 2)]
+    ref = []
+    for x, dy, k, s in cases:
+        dw = torch.empty(dy.shape[1], x.shape[1], k, k, device=DEV)
+        ops.conv_wgrad(x, dy, k, s, dw)
+        ref.append(dw)
+    out = [torch.full_like(r, float('nan')) for r in ref]
+    with ops.defer_wgrad():
+        for (x, dy, k, s), dw in zip(cases, out):
+            ops.conv_wgrad(x, dy, k, s, dw)
+        assert len(ops._WGRAD_PENDING) == len(cases)
+        x, dy, k, s = cases[0]
+        ops.conv_wgrad(x, dy, k, s, out[0], accumulate=True)                # flushes, then adds: out[0] = 2 * ref[0]
+        assert not ops._WGRAD_PENDING
+    for i, (o, r) in enumerate(zip(out, ref)):
+        assert torch.equal(o, r * 2 if i == 0 else r), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_stride2_data_gradient_phases(dtype):
+    """Data gradient of a stride-2 3x3 convolution = four stride-1 phase convolutions over dy whose K holds only the 1 / 2 / 4 taps the phase uses
+    (mgdt_conv2d_phase_fwd) against torch's conv_transpose2d in fp64; also with an accumulated addend (the shortcut fused into the epilogue)."""
+    from mgdt_yolo_amd import ops
+    gen = torch.Generator().manual_seed(13)
+    B, ci, co, H, W = 2, 32, 64, 20, 28
+    w = (torch.randn(co, ci, 3, 3, generator=gen) / 17).to(DEV)
+    dy = torch.randn(B, co, H // 2, W // 2, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    r2 = torch.randn(B, ci, H, W, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    wq = w.to(dtype).double() if dtype == torch.bfloat16 else w.double()
+    ref = torch.nn.functional.conv_transpose2d(dy.double(), wq, stride=2, padding=1, output_padding=1)
+    dx = ops.conv_dgrad(dy, w, 3, 2, ops.new_act(B, ci, H, W, dtype, DEV))
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert (dx.double() - ref).abs().max().item() < tol * ref.abs().max().item()
+    dx2 = ops.conv_dgrad(dy, w, 3, 2, ops.new_act(B, ci, H, W, dtype, DEV), r2=r2)
+    assert (dx2.double() - (ref + r2.double())).abs().max().item() < tol * (ref + r2.double()).abs().max().item()
