@@ -134,8 +134,27 @@ __device__ __forceinline__ V4Lerp v4_lerp_of(int o, int isz, int osz) {
 template <typename T>
 __global__ __launch_bounds__(256) void v4_bilinear_bwd_kernel(const mgdt_view gy, const mgdt_view gx, int accumulate) {
   const float ry = (float)gy.h / (float)gx.h, rx = (float)gy.w / (float)gx.w;
+  const bool x2 = gy.h == 2 * gx.h && gy.w == 2 * gx.w;       // exact 2x up-sampling: interior pixels have a fixed 4x4 stencil
   FOR_QUADS(gx) {
     DECODE_Q(i, gx, n, h, w, c)
+    if (x2 && h >= 1 && h < gx.h - 1 && w >= 1 && w < gx.w - 1) {
+      // src = o/2 - 0.25: outputs 2h-1, 2h, 2h+1, 2h+2 reach input h with weights 0.25, 0.75, 0.75, 0.25 (exactly what lerp_of yields there); same
+      // summation order as the generic scan below, so both paths give the same bits
+      const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+          const f32x4 g = load4<T>(P4(const T, gy, n, 2 * h - 1 + dy, 2 * w - 1 + dx, c));
+          const float ww = wt[dy] * wt[dx];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += ww * g[j];
+        }
+      if (accumulate) acc += load4<T>(P4(const T, gx, n, h, w, c));
+      store4<T>(P4(T, gx, n, h, w, c), acc);
+      continue;
+    }
     const int oy_lo = max(0, (int)floorf(((float)h - 1.f) * ry) - 1), oy_hi = min(gy.h - 1, (int)ceilf(((float)h + 2.f) * ry) + 1);
     const int ox_lo = max(0, (int)floorf(((float)w - 1.f) * rx) - 1), ox_hi = min(gy.w - 1, (int)ceilf(((float)w + 2.f) * rx) + 1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -1477,3 +1477,17 @@ def test_stride2_data_gradient_phases(dtype):
     assert (dx.double() - ref).abs().max().item() < tol * ref.abs().max().item()
     dx2 = ops.conv_dgrad(dy, w, 3, 2, ops.new_act(B, ci, H, W, dtype, DEV), r2=r2)
     assert (dx2.double() - (ref + r2.double())).abs().max().item() < tol * (ref + r2.double()).abs().max().item()
+
+
+@pytest.mark.gpu
+def test_bilinear_adjoint_2x_stencil_equals_generic_scan():
+    """The exact-2x fast path of the bilinear adjoint (fixed 4x4 stencil on interior pixels) against autograd of F.interpolate, fp32, and against a
+    non-2x shape that takes the generic candidate scan."""
+    from mgdt_yolo_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for (h, w, oh, ow) in ((10, 12, 20, 24), (10, 12, 23, 24)):
+        x = torch.randn(2, 8, h, w, generator=gen, requires_grad=True)
+        g = torch.randn(2, 8, oh, ow, generator=gen)
+        torch.nn.functional.interpolate(x, size=(oh, ow), mode='bilinear', align_corners=False).backward(g)
+        got = ops.bilinear_bwd(g.to(DEV).contiguous(memory_format=torch.channels_last), ops.new_act(2, 8, h, w, torch.float32, DEV))
+        np.testing.assert_allclose(to_nchw(got), x.grad.numpy(), atol=2e-6, rtol=2e-6)
