@@ -7,16 +7,28 @@
 
 #define BNF_SPLITS 512          // == RED_SPLITS of train.hip (the final kernels there sum this many partial rows)
 
+// exact-GELU pieces with ONE hardware exp2 + one rcp: e = exp(-u^2/2) serves both the normal density and Abramowitz-Stegun 7.1.26
+// erf(x) = 1 - (a1 t + .. + a5 t^5) exp(-x^2), t = 1/(1 + p x), x = |u|/sqrt(2)  (|error| < 1.5e-7: below fp32 round-off of the sums that consume it;
+// libm's erff + expf cost ~4x as many instructions and made the GELU passes of the ConvNeXt blocks VALU-bound)
+__device__ __forceinline__ void bnf_gelu_parts(float u, float& cdf, float& pdf) {
+  const float ax = fabsf(u) * 0.70710678118654752f;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);            // exp(-u^2 / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erfa = 1.f - poly * e;                                                  // erf(|u| / sqrt 2)
+  cdf = 0.5f * (1.f + (u < 0.f ? -erfa : erfa));
+  pdf = 0.3989422804014327f * e;
+}
 template <int ACT> __device__ __forceinline__ float bnf_act(float u) {
   if (ACT == MGDT_ACT_SILU) return u * fast_sigmoid(u);
   if (ACT == MGDT_ACT_RELU) return fmaxf(u, 0.f);
-  if (ACT == MGDT_ACT_GELU) return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+  if (ACT == MGDT_ACT_GELU) { float cdf, pdf; bnf_gelu_parts(u, cdf, pdf); return u * cdf; }
   return u;
 }
 template <int ACT> __device__ __forceinline__ float bnf_grad(float u) {
   if (ACT == MGDT_ACT_SILU) { const float s = fast_sigmoid(u); return s * (1.f + u * (1.f - s)); }
   if (ACT == MGDT_ACT_RELU) return u > 0.f ? 1.f : 0.f;
-  if (ACT == MGDT_ACT_GELU) return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+  if (ACT == MGDT_ACT_GELU) { float cdf, pdf; bnf_gelu_parts(u, cdf, pdf); return cdf + u * pdf; }
   return 1.f;
 }
 
