@@ -1,5 +1,6 @@
 // Shared device/host helpers for libmgdt_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -224,7 +224,7 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   if (nwg < a.ncg) return false;
 #define C3_LAUNCH(NB, ACTV, MTV)                                                                                          \
   {                                                                                                                  \
-    static bool attr = false, attr18 = false, attr23 = false;                                                                        \
+    static std::atomic<bool> attr{false}, attr18{false}, attr23{false};                                                                        \
     if (nchunks == 18) {                                                                                             \
       if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
       conv3x3_lds_kernel<NB, ACTV, 18, MTV><<<nwg, 256, lds, st>>>(a);                                                    \

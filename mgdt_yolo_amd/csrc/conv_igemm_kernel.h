@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
 
 template <typename T, int NT, int MT>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st) {
-  static bool attr_set = false;  // idempotent; racing setters write the same value
+  static std::atomic<bool> attr_set{false};  // idempotent; racing setters write the same value
   constexpr bool M1 = NT == 1;   // the segmented-panel variant exists for NT == 1 only (host never asks for it otherwise)
   const void* ks[8] = {(const void*)conv_igemm_kernel<T, NT, MT, 2, false, false>, (const void*)conv_igemm_kernel<T, NT, MT, 4, false, false>,
                        (const void*)conv_igemm_kernel<T, NT, MT, 2, true, false>,  (const void*)conv_igemm_kernel<T, NT, MT, 4, true, false>,

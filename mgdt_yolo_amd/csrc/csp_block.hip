@@ -504,7 +504,7 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   a.dbg = getenv("MGDT_CSP_DBG") ? dbgbuf : nullptr;
 #define CSP_LAUNCH(WDV, MODEV)                                                                                              \
   do {                                                                                                                      \
-    static bool attr = false;                                                                                               \
+    static std::atomic<bool> attr{false};                                                                                            \
     if (!attr) {                                                                                                            \
       hipError_t e_ = hipFuncSetAttribute((const void*)csp_block_kernel<WDV, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e_ != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "csp_block: hipFuncSetAttribute: %s", hipGetErrorString(e_));         \

@@ -160,7 +160,7 @@ extern "C" int mgdt_conv1x1_inject_supported(int cin, int cout, int h, int w, in
 
 template <int KC, int NB>
 static int inj_launch(const InjArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_inject_kernel<bf16, KC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv1x1_inject: hipFuncSetAttribute: %s", hipGetErrorString(e));

@@ -343,7 +343,7 @@ static int mlp_launch(MlpArgs& a, const float* gamma, const float* beta, float* 
   const size_t w1b = mlp_w1_bytes(KC1), w2b = mlp_w2_bytes(KC1);
   const size_t lds_b = (size_t)(HD + 2 * KC1 * 16 + 4) * sizeof(float);
   const size_t lds_s = w1b + (size_t)(MLP_THREADS / 64) * HD * sizeof(float) + lds_b, lds_a = w1b + w2b + (size_t)2 * HD * sizeof(float) + lds_b;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     for (const void* k : {(const void*)cnx_mlp_kernel<bf16, KC1, MT, true>, (const void*)cnx_mlp_kernel<bf16, KC1, MT, false>}) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

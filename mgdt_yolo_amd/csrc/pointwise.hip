@@ -1191,7 +1191,7 @@ extern "C" int mgdt_detect_decode_fwd(const mgdt_view* feat, int reg_max, int nc
   size_t lds = (size_t)DEC_A * (no + 1) * sizeof(float);
   if (vec4_ok(feat, dtype) && lds <= 144 * 1024) {
     if (lds > 64 * 1024) {      // reg_max = 16 heads (TOODHead): the transposed tile needs more than the default dynamic LDS limit
-      static bool attr_set = false;
+      static std::atomic<bool> attr_set{false};
       if (!attr_set) {
         for (const void* k : {(const void*)detect_decode_tile_kernel<float>, (const void*)detect_decode_tile_kernel<bf16>}) {
           hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
