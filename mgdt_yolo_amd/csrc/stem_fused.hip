@@ -56,13 +56,29 @@ __global__ __launch_bounds__(256) void stem2_kernel(const StemArgs a) {
   const int iy0 = 4 * ty0 - 3, ix0 = 4 * tx0 - 8;
   const TX* xb = (const TX*)a.x + (long)n * a.xsn;
   if (a.fast) {                  // bf16 image, rows contiguous and 16-byte aligned, W % 8 == 0: whole 8-element vectors are inside or outside
-    for (int i = tid; i < 3 * ST_XH * (ST_XWV / 8); i += 256) {
+    // all of a thread's 16-byte requests are issued before the first LDS store (clamped address, zeroed afterwards when outside the image): with a
+    // bounds test around each load the 4-5 requests of a thread ran as dependent round trips
+    constexpr int NI = 3 * ST_XH * (ST_XWV / 8), NU = (NI + 255) / 256;
+    uint4 val[NU];
+    bool inb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = min(tid + u * 256, NI - 1);
       const int pl = i / (ST_XH * (ST_XWV / 8)), rem = i - pl * (ST_XH * (ST_XWV / 8));
       const int row = rem / (ST_XWV / 8), seg = rem - row * (ST_XWV / 8);
       const int iy = iy0 + row, ix = ix0 + seg * 8;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)iy < (unsigned)a.H && ix >= 0 && ix + 8 <= a.W) val = *(const uint4*)(xb + (long)pl * a.xsc + (long)iy * a.xsh + ix);
-      *(uint4*)&X[pl][row][seg * 8] = val;
+      inb[u] = (unsigned)iy < (unsigned)a.H && ix >= 0 && ix + 8 <= a.W;
+      const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 8);
+      val[u] = *(const uint4*)(xb + (long)pl * a.xsc + (long)iyc * a.xsh + ixc);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = tid + u * 256;
+      if (i < NI) {
+        const int pl = i / (ST_XH * (ST_XWV / 8)), rem = i - pl * (ST_XH * (ST_XWV / 8));
+        const int row = rem / (ST_XWV / 8), seg = rem - row * (ST_XWV / 8);
+        *(uint4*)&X[pl][row][seg * 8] = inb[u] ? val[u] : make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   } else {
     if constexpr (std::is_same<TX, uint8_t>::value) __syncthreads();      // lut
