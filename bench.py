@@ -228,7 +228,7 @@ def main():
         cfg = get_config(args.model, args.scale, nc)
         model = seed_state_dict_(DetectionModel(cfg, verbose=False), 0).to(dev)
         # bf16: activations / activation gradients in bf16, fp32 masters.  Single rank: the step is captured in a hipGraph after the first optimizer step
-        tr = DetectionTrainer(model, world_size=world, amp=args.dtype == 'bf16', graph=not args.no_graph and world == 1)
+        tr = DetectionTrainer(model, world_size=world, amp=args.dtype == 'bf16', graph=not args.no_graph)
         graph_used = tr.graph
         R = max(1, min(args.resident, 4))
         batches = []
@@ -251,7 +251,7 @@ def main():
         x_desc = 'uint8 NCHW images resident in HBM (/255 fused into the stem), synthetic labels (1-20 boxes / image)'
         workload = (f'{args.model}-{args.scale} (nc=80) {args.imgsz}x{args.imgsz} TRAINING step, batch {args.batch}/GPU (global {world * args.batch}): '
                     'train-mode forward (batch-stat BN) + fused assigner/loss + HIP reverse pass + bucketed RCCL all-reduce of the flat gradient buffer '
-                    '+ clip/SGD(nesterov)/EMA' + ('; whole step replayed as one hipGraph' if graph_used else '') + '; BASELINE configs[2]')
+                    '+ clip/SGD(nesterov)/EMA' + (('; whole step replayed as one hipGraph' if world == 1 else '; step replayed as two hipGraphs around the flat-gradient all-reduce') if graph_used else '') + '; BASELINE configs[2]')
         metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, data-parallel training step'
         parallelism = f'dp{world} (batch-sharded, one flat-gradient all-reduce per step over RCCL/xGMI)' if world > 1 else 'dp1 (no collective)'
         n_det = None

@@ -191,12 +191,18 @@ class MSPA_C2f(HipModule):
         wd, s, n = self.inwidth, self.nums, self.btnk_nums
         at = self.attention
         dattn = ops.nc_reduce(g, out)                               # d/d attn[n,c] = sum_hw g*out
-        gout, pg = ops.spr_bwd(g, part, attn, dattn, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
-        cw = wd
-        hid = cw // 4
-        o1, o2, o3 = hid * 5 * cw, hid * 5 * cw + hid, hid * 5 * cw + hid + cw * hid
-        for prm, seg in ((at.fc1.weight, pg[:o1]), (at.fc1.bias, pg[o1:o2]), (at.fc2.weight, pg[o2:o3]), (at.fc2.bias, pg[o3:])):
-            ops.grad_buf(prm).copy_(seg.view_as(prm))       # four tiny device-to-device copies into the (flat) gradient buffer
+        prms = (at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias)
+        gb = [ops.grad_buf(p) for p in prms]
+        # the trainer's flat gradient buffer holds the four tensors back to back in this order: the kernel writes its [dW1|db1|dW2|db2] there
+        chained = all(t.is_contiguous() and t.dtype == torch.float32 for t in gb) and all(
+            a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.storage_offset() + a.numel() == b.storage_offset() for a, b in zip(gb, gb[1:]))
+        pg_out = gb[0].new_empty(0).set_(gb[0].untyped_storage(), gb[0].storage_offset(), (sum(t.numel() for t in gb),)) if chained else None
+        gout, pg = ops.spr_bwd(g, part, attn, dattn, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, out=pg_out)
+        if not chained:
+            o = 0
+            for prm, t in zip(prms, gb):
+                t.copy_(pg[o:o + t.numel()].view_as(prm))
+                o += t.numel()
         gcat = self.convs[s - 1].backward(gout)
         gx = ops.new_act(xshape[0], xshape[1], xshape[2], xshape[3], g.dtype, g.device)
         sl = lambda t, i: t[:, i * wd:(i + 1) * wd]

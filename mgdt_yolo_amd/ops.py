@@ -952,13 +952,15 @@ def spr_attention_train(x, fc1_w, fc1_b, fc2_w, fc2_b, groups):
     return attn, part
 
 
-def spr_bwd(gy, part, attn, dattn, fc1_w, fc1_b, fc2_w, fc2_b, groups):
-    """Returns (grad w.r.t. the pre-scale map, flat fp32 param grads [dW1 | db1 | dW2 | db2])."""
+def spr_bwd(gy, part, attn, dattn, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None):
+    """Returns (grad w.r.t. the pre-scale map, flat fp32 param grads [dW1 | db1 | dW2 | db2]); `out`: where to write the latter."""
     b, c = gy.shape[:2]
     lib = L.lib()
     cw = c // groups
     hid = cw // 4
-    pg = torch.empty(hid * 5 * cw + hid + cw * hid + cw, dtype=torch.float32, device=gy.device)
+    n_pg = hid * 5 * cw + hid + cw * hid + cw
+    assert out is None or (out.numel() == n_pg and out.dtype == torch.float32 and out.is_contiguous())
+    pg = torch.empty(n_pg, dtype=torch.float32, device=gy.device) if out is None else out
     ws = torch.empty(lib.mgdt_spr_bwd_workspace_bytes(b, c, groups), dtype=torch.uint8, device=gy.device)
     gx = like(gy)
     _launch('spr_bwd', 'mgdt_spr_bwd', vp(gy), ptr(part), L.SPR_SPLITS, ptr(attn), ptr(dattn), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups,

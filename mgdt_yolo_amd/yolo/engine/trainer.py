@@ -118,7 +118,7 @@ class DetectionTrainer:
 
     def __init__(self, model, lr0=0.001, lrf=0.01, momentum=0.937, weight_decay=5e-4, world_size=1, ema_decay=0.9999, ema_tau=2000.0,
                  batch_size=None, nb=None, epochs=100, nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, overlap=True, amp=False,
-                 graph=False):
+                 graph=False, graph_split=None):
         self.model = model.train()
         # amp: the reference trains under autocast (trainer.py:223,329: fp16 + GradScaler); on this hardware the reduced-precision training path
         # is bfloat16 activations / gradients with fp32 master weights, fp32 accumulation and fp32 weight gradients - no loss scaling needed
@@ -141,8 +141,11 @@ class DetectionTrainer:
         self.ni, self.last_opt_step, self.lr, self.lr_bias, self.mom = 0, -1, lr0, lr0, momentum
         # graph=True: from the second optimizer step on, the whole step (forward, loss, reverse pass, clip + SGD + EMA: ~500 launches) is one
         # hipGraph replay; lr / momentum / EMA decay / the assigner's call counter live in device memory so that the warm-up schedule and the
-        # EMA ramp keep advancing between replays.  Single-rank, accumulate == 1 only (otherwise the eager path runs).
+        # EMA ramp keep advancing between replays.  accumulate == 1 only (otherwise the eager path runs).  With several ranks (or
+        # graph_split=True) the step is captured as TWO graphs - forward/loss/reverse pass, then clip/SGD/EMA/re-pack - with the one
+        # flat-gradient all-reduce issued eagerly between the two replays (RCCL is not captured).
         self.graph = bool(graph)
+        self.graph_split = parallel.world() > 1 if graph_split is None else bool(graph_split)
         self._graphs, self._pool, self._static = {}, None, None
         self.exchange = None
         if parallel.world() > 1:
@@ -185,20 +188,24 @@ class DetectionTrainer:
 
     # ---- captured step -------------------------------------------------------------------------------------------------------------
     def _graph_ok(self):
-        return (self.graph and parallel.world() == 1 and self.state.steps >= 1 and self.accumulate == 1
+        return (self.graph and self.state.steps >= 1 and self.accumulate == 1
                 and (self.batch_size is None or self.nbs / self.batch_size <= 1.0))
 
-    def _graph_body(self):
+    def _graph_body(self, part=None):
+        """part None: the whole step; 'grad': forward + loss + reverse pass; 'update': clip + SGD + EMA + re-pack."""
         st, S = self.state, self._static
-        feats = self.model._predict_once(S['img'])
-        ls = ops.detect_loss_fwd(list(feats), self.crit.stride_list, self.crit.reg_max, self.crit.nc, S['gt'], 0,
-                                 (self.crit.hyp.box, self.crit.hyp.cls, self.crit.hyp.dfl), call_count_dev=S['calls'])
-        grads = ops.detect_loss_bwd(ls, float(self.world_size))
-        self.model.backward(grads)
+        if part != 'update':
+            feats = self.model._predict_once(S['img'])
+            ls = ops.detect_loss_fwd(list(feats), self.crit.stride_list, self.crit.reg_max, self.crit.nc, S['gt'], 0,
+                                     (self.crit.hyp.box, self.crit.hyp.cls, self.crit.hyp.dfl), call_count_dev=S['calls'])
+            grads = ops.detect_loss_bwd(ls, float(self.world_size))
+            self.model.backward(grads)
+            S['out5'] = ls.out5
+            if part == 'grad':
+                return
         clip = ops.grad_clip_coef(st.grad, 10.0)
         ops.sgd_ema_step_dev(st.data[:st.n_param], st.grad, st.momentum_buf, st.wd, st.ema, st.data, S['hyper'], True, False, clip)
         ops.repack_all()                            # next step's packed weights, all convolutions in a few launches
-        S['out5'] = ls.out5
 
     def _graph_step(self, batch):
         st = self.state
@@ -222,15 +229,22 @@ class DetectionTrainer:
         S['hyper'].copy_(torch.tensor([self.lr, self.lr_bias, self.mom, d], dtype=torch.float32), non_blocking=True)
         S['calls'].fill_(int(self.crit.epoch))
         if nmax not in self._graphs:
-            g = torch.cuda.CUDAGraph()
+            gs = []
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self._pool):
-                self._graph_body()
-            if self._pool is None:
-                self._pool = g.pool()
-            self._graphs[nmax] = (g, S['out5'])
-        g, out5 = self._graphs[nmax]
-        g.replay()
+            for part in (('grad', 'update') if self.graph_split else (None,)):
+                g = torch.cuda.CUDAGraph()
+                # several ranks: the RCCL watchdog thread polls events while we capture, so only this thread's calls are checked
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local' if parallel.world() > 1 else 'global'):
+                    self._graph_body(part)
+                if self._pool is None:
+                    self._pool = g.pool()
+                gs.append(g)
+            self._graphs[nmax] = (gs, S['out5'])
+        gs, out5 = self._graphs[nmax]
+        gs[0].replay()
+        if self.graph_split:
+            parallel.all_reduce_mean_(st.grad)       # one flat message between the two replays (loss was scaled by world_size: trainer.py:337-338)
+            gs[1].replay()
         ops.PARAM_EPOCH[0] += 1                     # the replay moved the weights: packed-weight caches of any eager forward are stale
         st.steps += 1
         self.crit.epoch += 1

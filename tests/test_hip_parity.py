@@ -1248,12 +1248,13 @@ def test_bf16_mfma_weight_gradient(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('amp', [False, True], ids=['f32', 'bf16'])
-def test_captured_training_step_equals_the_eager_step(amp):
+@pytest.mark.parametrize('amp,split', [(False, False), (True, False), (True, True)], ids=['f32', 'bf16', 'bf16-two-graphs'])
+def test_captured_training_step_equals_the_eager_step(amp, split):
     """DetectionTrainer(graph=True): after the first optimizer step the whole step (forward, assigner + loss, reverse pass, clip + SGD + EMA)
     is one hipGraph replay with lr / bias lr / momentum / EMA decay / the assigner's call counter read from device memory.  Six steps over
     three different batches (different label counts -> the padded label slots differ, warm-up changes lr every step) must give the same
-    losses, weights and EMA as the eager launches: bit-equal, every kernel has a fixed summation order."""
+    losses, weights and EMA as the eager launches: bit-equal, every kernel has a fixed summation order.  'two-graphs' is the multi-rank
+    form (forward/loss/reverse pass | flat-gradient all-reduce, eager | clip/SGD/EMA/re-pack) forced on one rank."""
     from mgdt_yolo_amd.nn.tasks import DetectionModel
     from mgdt_yolo_amd.seeding import seeded_labels
     from mgdt_yolo_amd.yolo.engine.trainer import DetectionTrainer
@@ -1266,11 +1267,12 @@ def test_captured_training_step_equals_the_eager_step(amp):
     res = {}
     for graph in (False, True):
         m = seed_state_dict_(DetectionModel(get_config('mspa_c2f_gd_yolov8', 'n', nc), verbose=False), 0).to(DEV)
-        tr = DetectionTrainer(m, lr0=0.01, amp=amp, graph=graph, batch_size=64, nb=10, epochs=3)       # nbs / batch = 1: accumulate stays 1; warm-up active
+        tr = DetectionTrainer(m, lr0=0.01, amp=amp, graph=graph, graph_split=split, batch_size=64, nb=10, epochs=3)       # nbs / batch = 1: accumulate stays 1; warm-up active
         losses = [tr.step(batches[i % 3])[0].item() for i in range(6)]
         res[graph] = (losses, tr.state.data.clone(), tr.state.ema.clone(), tr.state.steps, tr.crit.epoch)
         if graph:
             assert len(tr._graphs) >= 1, 'the captured path did not run'
+            assert all(len(gs) == (2 if split else 1) for gs, _ in tr._graphs.values())
     (l0, w0, e0, s0, c0), (l1, w1, e1, s1, c1) = res[False], res[True]
     assert s0 == s1 == 6 and c0 == c1 == 6
     assert l0 == l1, (l0, l1)
