@@ -286,6 +286,13 @@ int mgdt_bn_act_bwd(const mgdt_view* gz, const mgdt_view* y, const float* mean, 
                     const float* beta, int act, float* dgamma, float* dbeta, const mgdt_view* dy, void* ws, int dtype, mgdt_stream s);
 int mgdt_conv_dgrad(const mgdt_view* dy, const float* w_oihw, int k, int stride, const mgdt_view* dx, int accumulate, int dtype,
                     mgdt_stream s);
+/* Grouped / depth-wise convolution (the reference's DWConv, nn/modules/conv.py:82-86; Conv with g > 1): data and weight gradients.
+   w / dw: [cout][cin/groups][k][k] fp32 (nn.Conv2d's layout); NHWC views; plain VALU kernels (no target YAML instantiates a grouped conv). */
+int mgdt_gconv_dgrad(const mgdt_view* dy, const float* w, int k, int stride, int groups, const mgdt_view* dx, int accumulate, int dtype,
+                     mgdt_stream s);
+size_t mgdt_gconv_wgrad_workspace_bytes(int cin, int cout, int k, int groups);
+int mgdt_gconv_wgrad(const mgdt_view* x, const mgdt_view* dy, int k, int stride, int groups, float* dw, int accumulate, void* ws, int dtype,
+                     mgdt_stream s);
 size_t mgdt_conv_wgrad_workspace_bytes(int cin, int cout, int k);
 int mgdt_conv_wgrad(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* dw_oihw, float* dbias,
                     int accumulate, void* ws, int dtype, mgdt_stream s);

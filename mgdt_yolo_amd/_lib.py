@@ -103,6 +103,9 @@ PROTOTYPES = {
     'mgdt_bn_act_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _i, VP, VP, VP, _i, _vp]),
     'mgdt_bn_act_bwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _vp, _vp, VP, _vp, _i, _vp]),
     'mgdt_conv_dgrad': (_i, [VP, _vp, _i, _i, VP, _i, _i, _vp]),
+    'mgdt_gconv_dgrad': (_i, [VP, _vp, _i, _i, _i, VP, _i, _i, _vp]),
+    'mgdt_gconv_wgrad_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'mgdt_gconv_wgrad': (_i, [VP, VP, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'mgdt_conv_wgrad_workspace_bytes': (_sz, [_i, _i, _i]),
     'mgdt_conv_wgrad': (_i, [VP, VP, VP, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     'mgdt_add_fwd': (_i, [VP, VP, VP, _i, _vp]),

@@ -661,3 +661,91 @@ extern "C" int mgdt_nearest_bwd(const mgdt_view* gy, const mgdt_view* gx, int dt
   MGDT_CHECK_LAUNCH("nearest_bwd");
   return MGDT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ grouped / depth-wise convolution (DWConv, conv.py:82-86)
+// Not on any target YAML: plain VALU kernels, one thread per element, so that training a model that holds a DWConv is served instead of refused.
+// w: [cout][cin/groups][k][k] fp32 (nn.Conv2d's layout for groups > 1).
+#define GC_SPLITS 64
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_dgrad_kernel(const mgdt_view dy, const float* __restrict__ w, int KS, int stride, int groups, const mgdt_view dx,
+                                                          int accumulate) {
+  const int cig = dx.c / groups, cog = dy.c / groups, pad = KS / 2;
+  const long total = (long)dx.n * dx.h * dx.w * dx.c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % dx.c);
+    long t = i / dx.c;
+    const int ix = (int)(t % dx.w);
+    t /= dx.w;
+    const int iy = (int)(t % dx.h);
+    const long n = t / dx.h;
+    const int g = ci / cig, cl = ci - g * cig;
+    float acc = 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+      const int ty = iy + pad - ky;
+      if (ty < 0 || ty % stride || ty / stride >= dy.h) continue;
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tx = ix + pad - kx;
+        if (tx < 0 || tx % stride || tx / stride >= dy.w) continue;
+        const T* gp = (const T*)dy.p + n * dy.sn + (long)(ty / stride) * dy.sh + (long)(tx / stride) * dy.sw + g * cog;
+        for (int co = 0; co < cog; ++co) acc = fmaf(ldf<T>(gp + co), w[(((long)(g * cog + co) * cig + cl) * KS + ky) * KS + kx], acc);
+      }
+    }
+    T* op = (T*)dx.p + n * dx.sn + (long)iy * dx.sh + (long)ix * dx.sw + ci;
+    if (accumulate) acc += ldf<T>(op);
+    stf<T>(op, acc);
+  }
+}
+
+// thread = one weight element x one pixel split; partial[split][cout * cin/groups * k * k]
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_wgrad_partial_kernel(const mgdt_view x, const mgdt_view dy, int KS, int stride, int groups, float* __restrict__ partial,
+                                                                  int nel) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nel) return;
+  const int cig = x.c / groups, cog = dy.c / groups, pad = KS / 2;
+  const int kx = e % KS, ky = (e / KS) % KS, cl = (e / (KS * KS)) % cig, co = e / (KS * KS * cig);
+  const int ci = (co / cog) * cig + cl;
+  const long npix = (long)dy.n * dy.h * dy.w, per = (npix + GC_SPLITS - 1) / GC_SPLITS;
+  const long p0 = blockIdx.y * per, p1 = p0 + per < npix ? p0 + per : npix;
+  float acc = 0.f;
+  for (long p = p0; p < p1; ++p) {
+    const int ox = (int)(p % dy.w);
+    const long t = p / dy.w;
+    const int oy = (int)(t % dy.h);
+    const long n = t / dy.h;
+    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    if (iy < 0 || iy >= x.h || ix < 0 || ix >= x.w) continue;
+    acc = fmaf(ldf<T>((const T*)dy.p + n * dy.sn + (long)oy * dy.sh + (long)ox * dy.sw + co),
+               ldf<T>((const T*)x.p + n * x.sn + (long)iy * x.sh + (long)ix * x.sw + ci), acc);
+  }
+  partial[(long)blockIdx.y * nel + e] = acc;
+}
+
+extern "C" size_t mgdt_gconv_wgrad_workspace_bytes(int cin, int cout, int k, int groups) {
+  return groups > 0 ? (size_t)GC_SPLITS * cout * (cin / groups) * k * k * sizeof(float) : 0;
+}
+
+extern "C" int mgdt_gconv_dgrad(const mgdt_view* dy, const float* w, int k, int stride, int groups, const mgdt_view* dx, int accumulate, int dtype, mgdt_stream s) {
+  if (!view_ok(dy) || !view_ok(dx) || !w) MGDT_FAIL(MGDT_BAD_ARG, "gconv_dgrad: null/empty argument");
+  if (groups < 1 || dx->c % groups || dy->c % groups || dy->sc != 1 || dx->sc != 1 || dy->n != dx->n) MGDT_FAIL(MGDT_BAD_SHAPE, "gconv_dgrad: NHWC views, channels %% groups == 0");
+  const int pad = k / 2;
+  if ((dx->h + 2 * pad - k) / stride + 1 != dy->h || (dx->w + 2 * pad - k) / stride + 1 != dy->w) MGDT_FAIL(MGDT_BAD_SHAPE, "gconv_dgrad: dy/dx geometry mismatch");
+  const long total = (long)dx->n * dx->h * dx->w * dx->c;
+  MGDT_DISPATCH_DTYPE(dtype, (gconv_dgrad_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)s>>>(*dy, w, k, stride, groups, *dx, accumulate)));
+  MGDT_CHECK_LAUNCH("gconv_dgrad");
+  return MGDT_OK;
+}
+
+extern "C" int mgdt_gconv_wgrad(const mgdt_view* x, const mgdt_view* dy, int k, int stride, int groups, float* dw, int accumulate, void* ws, int dtype,
+                                mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(dy) || !dw || !ws) MGDT_FAIL(MGDT_BAD_ARG, "gconv_wgrad: null/empty argument");
+  if (groups < 1 || x->c % groups || dy->c % groups || dy->sc != 1 || x->sc != 1 || dy->n != x->n) MGDT_FAIL(MGDT_BAD_SHAPE, "gconv_wgrad: NHWC views, channels %% groups == 0");
+  const int pad = k / 2;
+  if ((x->h + 2 * pad - k) / stride + 1 != dy->h || (x->w + 2 * pad - k) / stride + 1 != dy->w) MGDT_FAIL(MGDT_BAD_SHAPE, "gconv_wgrad: x/dy geometry mismatch");
+  const int nel = dy->c * (x->c / groups) * k * k;
+  hipStream_t st = (hipStream_t)s;
+  MGDT_DISPATCH_DTYPE(dtype, (gconv_wgrad_partial_kernel<T><<<dim3(cdiv(nel, 256), GC_SPLITS), 256, 0, st>>>(*x, *dy, k, stride, groups, (float*)ws, nel)));
+  wgrad_final_kernel<<<cdiv(nel, 64), 256, 0, st>>>((const float*)ws, nel, dw, accumulate, GC_SPLITS);
+  MGDT_CHECK_LAUNCH("gconv_wgrad");
+  return MGDT_OK;
+}

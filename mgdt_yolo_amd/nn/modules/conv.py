@@ -116,9 +116,6 @@ class Conv(HipModule):
         """act(bn_batchstats(conv(x [+ x2]))) [+ r1] [+ r2]; keeps (x, x2, raw conv output, mean, rstd) for backward()."""
         k, s = self._geometry()
         dt = self.out_dtype(x) if out is None else out.dtype
-        if self.conv.groups != 1:
-            raise NotImplementedError('grouped / depth-wise Conv has no training kernels (weight and data gradients assume groups == 1); '
-                                      'DWConv is not instantiated by any target YAML')
         mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
         pk = self._cached(('raw', dt, not mfma), [self.conv.weight],
                           lambda: ops.PackedConv(self.conv.weight, None, None, k, dt, direct=not mfma, groups=self.conv.groups))
@@ -135,9 +132,9 @@ class Conv(HipModule):
         """gz: grad w.r.t. the pre-residual output.  Fills .grad of conv.weight / bn.weight / bn.bias (overwrite), returns dx
         (written into the view `dx_out` when given; `acc`: added to what dx_out holds; `r2`: one more addend, e.g. a shortcut's gradient -
         both fused into the data-gradient convolution's epilogue)."""
-        if self.conv.groups != 1:
-            raise NotImplementedError('grouped / depth-wise Conv has no backward kernels')
         x, x2, y, mean, rstd, k, s = self._ctx.pop()
+        if self.conv.groups != 1:
+            return self._backward_grouped(gz, x, y, mean, rstd, k, s, need_dx, dx_out, acc, r2)
         bn = self.bn
         ops.grad_buf(bn.weight)
         ops.grad_buf(bn.bias)
@@ -148,6 +145,17 @@ class Conv(HipModule):
             return None
         dx = dx_out if dx_out is not None else ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
         return ops.conv_dgrad(dy, self.conv.weight, k, s, dx, accumulate=bool(acc and dx_out is not None), r2=r2)
+
+    def _backward_grouped(self, gz, x, y, mean, rstd, k, s, need_dx, dx_out, acc, r2):
+        """DWConv / Conv with g > 1 (conv.py:82-86): the grouped VALU kernels (weight [cout][cin/g][k][k]); not on any target YAML."""
+        bn, g = self.bn, self.conv.groups
+        dy = ops.bn_act_bwd(gz, y, mean, rstd, bn.weight, bn.bias, act_code(self.act), ops.grad_buf(bn.weight), ops.grad_buf(bn.bias))
+        ops.gconv_wgrad(x, dy, k, s, g, ops.grad_buf(self.conv.weight))
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else ops.new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], dy.dtype, dy.device)
+        ops.gconv_dgrad(dy, self.conv.weight, k, s, g, dx, accumulate=bool(acc and dx_out is not None))
+        return dx if r2 is None else ops.add(dx, r2, out=dx)
 
     def forward_fuse(self, x):
         """After BaseModel.fuse(): `bn` is gone and `conv` carries the folded weight + bias (conv.py:40-42)."""

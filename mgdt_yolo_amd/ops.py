@@ -826,6 +826,23 @@ def conv_dgrad(dy, weight, k, stride, dx, accumulate=False, r2=None):
     return dx if r2 is None else add(dx, r2, out=dx)
 
 
+def gconv_dgrad(dy, weight, k, stride, groups, dx, accumulate=False):
+    """Grouped / depth-wise data gradient (DWConv, conv.py:82-86).  weight: [cout][cin/groups][k][k] fp32."""
+    _same(dy, dx)
+    _launch('conv_dgrad', 'mgdt_gconv_dgrad', vp(dy), ptr(weight), k, stride, groups, vp(dx), int(accumulate), dtype_code(dy.dtype), stream())
+    return dx
+
+
+def gconv_wgrad(x, dy, k, stride, groups, dw, accumulate=False):
+    """Grouped / depth-wise weight gradient into dw ([cout][cin/groups][k][k] fp32)."""
+    _same(x, dy)
+    assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == dy.shape[1] * (x.shape[1] // groups) * k * k
+    flush_wgrad()                                   # deferred final sums of earlier convolutions read their own workspaces: keep the order simple
+    ws = torch.empty(L.lib().mgdt_gconv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k, groups), dtype=torch.uint8, device=x.device)
+    _launch('conv_wgrad', 'mgdt_gconv_wgrad', vp(x), vp(dy), k, stride, groups, ptr(dw), int(accumulate), ptr(ws), dtype_code(dy.dtype), stream())
+    return dw
+
+
 def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
     lib = L.lib()
     if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype in (torch.float32, torch.uint8) and x2 is None and not accumulate and x.shape[1] < 4:

@@ -412,13 +412,42 @@ def test_tood_scale_s_at_1280_properties():
     assert len(kept2[0]) == len(kept[0]) and torch.equal(rows2[0], rows[0])
 
 
-def test_dwconv_has_no_training_kernels_and_says_so():
-    """Grouped convs are inference-only (weight / data gradient kernels assume groups == 1): train mode must refuse, not corrupt memory."""
+@pytest.mark.parametrize('c1,c2,k,s,dt', [(16, 16, 3, 1, torch.float32), (16, 32, 5, 2, torch.float32), (24, 36, 3, 1, torch.float32), (32, 32, 3, 2, torch.bfloat16)],
+                         ids=['depthwise3', 'dw5s2_mult2', 'groups12', 'depthwise3s2_bf16'])
+def test_dwconv_trains_against_torch_autograd(c1, c2, k, s, dt):
+    """DWConv (reference conv.py:82-86: Conv with g = gcd(c1, c2)) in training mode: batch-stat BN forward, then the grouped data / weight
+    gradient kernels, against torch.autograd of conv2d(groups) -> batch_norm(training) -> SiLU in float64 on the CPU."""
+    import torch.nn.functional as F
     from mgdt_yolo_amd.nn.modules import DWConv
-    m = seed_state_dict_(DWConv(16, 32, 3, 1), 1).to(DEV).train()
-    x = torch.randn(2, 16, 9, 9, device=DEV).contiguous(memory_format=torch.channels_last)
-    with pytest.raises(NotImplementedError, match='grouped'):
-        m(x)
+    m = seed_state_dict_(DWConv(c1, c2, k, s), 1)
+    g = m.conv.groups
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, c1, 11, 9, generator=gen)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    w = m.conv.weight.detach().double().requires_grad_(True)
+    ga, be = m.bn.weight.detach().double().requires_grad_(True), m.bn.bias.detach().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    y_ref = F.silu(F.batch_norm(F.conv2d(xr, w, None, s, k // 2, 1, g), None, None, ga, be, True, 0.0, m.bn.eps))
+    gy = torch.randn(y_ref.shape, generator=gen)
+    if dt == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    (y_ref * gy.double()).sum().backward()
+    m = m.to(DEV).train()
+    nh = lambda t: t.to(DEV).to(dt).contiguous(memory_format=torch.channels_last)
+    y = m(nh(x))
+    tol = 3e-2 if dt == torch.bfloat16 else 2e-4
+    rel = lambda a, b: (a.double().cpu() - b.double()).norm().item() / b.double().norm().item()
+    assert rel(y.float(), y_ref.detach()) < tol
+    dx = m.backward(nh(gy))
+    assert rel(dx.float(), xr.grad) < tol, rel(dx.float(), xr.grad)
+    assert rel(m.conv.weight.grad, w.grad) < tol, rel(m.conv.weight.grad, w.grad)
+    assert rel(m.bn.weight.grad, ga.grad) < tol and rel(m.bn.bias.grad, be.grad) < tol
+    # accumulate form of the data gradient (a fan-in sum): dx_out holds an addend
+    m(nh(x))
+    base = torch.randn(dx.shape, generator=gen).to(DEV).to(dt).contiguous(memory_format=torch.channels_last)
+    dx2 = m.backward(nh(gy), dx_out=base.clone(memory_format=torch.channels_last), acc=True)
+    assert rel(dx2.float(), xr.grad + base.double().cpu()) < tol
 
 
 # ------------------------------------------------------------------------------------------------ conv kernel sweep
