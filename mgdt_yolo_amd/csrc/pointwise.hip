@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_tiled_kernel(const T* __restri
 // 14 halo values of its row once and reuses each for up to 7 of its 8 outputs from registers: 4x fewer LDS reads and bf16->fp32
 // conversions than one-pixel-per-iteration, 8 independent accumulators of ILP.  LayerNorm: per-pixel partials -> 64 threads
 // reduce over the quads -> broadcast, twice (mean, then centred variance: the two-pass form F.layer_norm uses).
-template <typename T>
+template <typename T, int TS>
 __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw,
                                                              const float* __restrict__ dw, const float* __restrict__ db,
                                                              const float* __restrict__ lw, const float* __restrict__ lb, float eps,
@@ -869,54 +869,51 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
   if (dbgw) TT[0] = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) char smem_dw[];
   const int Q = C / 4;                                  // blockDim.x == 8 * Q
-  constexpr int HH = DW_TH + 6, HW_ = DW_TW + 6, NPIX = DW_TH * DW_TW;
+  constexpr int HH = TS + 6, HW_ = TS + 6, NPIX = TS * TS;
   T* halo = (T*)smem_dw;                                // [HH][HW_][C]
   float* wl = (float*)(smem_dw + (((size_t)HH * HW_ * C * sizeof(T) + 15) & ~(size_t)15));   // [49][C]
   float* red = wl + 49 * C;                             // [NPIX][Q] partial sums (reused for mean and variance)
   float* stat = red + NPIX * Q;                         // [NPIX] mean, then rstd
-  const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
+  const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
   const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
-  const int ty0 = (tr / tiles_x) * DW_TH, tx0 = (tr % tiles_x) * DW_TW;
+  const int ty0 = (tr / tiles_x) * TS, tx0 = (tr % tiles_x) * TS;
   const int q = threadIdx.x % Q, row = threadIdx.x / Q;
   // stage the halo (zero padding outside the image); q, row fixed per thread.  Loads are issued before their LDS
   // stores so that a thread has all its 25 global requests in flight at once (one round trip instead of 25 dependent ones: with two
   // workgroups per CU there is nobody else to hide that latency).
-  constexpr int NST = (HH * HW_ + DW_TH - 1) / DW_TH;
+  constexpr int NST = (HH * HW_ + TS - 1) / TS;
   {
     // branch-free: out-of-image pixels get an out-of-range offset of a bounds-checked descriptor (zeros come back), so all NST loads of a
     // thread are issued back to back
     const long ext = ((long)(H - 1) * xsh + (long)(W - 1) * xsw + C) * (long)sizeof(T);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + n * xsn), 0, (int)ext, 0x00020000);
-    f32x4 v[NST];
+    using raw_t = typename std::conditional<sizeof(T) == 2, bf16x4, f32x4>::type;      // staged as loaded (no fp32 round trip)
+    raw_t v[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int p = row + i * DW_TH;
+      const int p = row + i * TS;
       const int hy = p / HW_, hx = p % HW_;
       const int iy = ty0 + hy - 3, ix = tx0 + hx - 3;
       const bool ok = p < HH * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       const uint32_t off = ok ? (uint32_t)((iy * xsh + ix * xsw + q * 4) * (long)sizeof(T)) : 0x80000000u;
-      if constexpr (sizeof(T) == 2) {
-        const bf16x4 r4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
-        v[i] = f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
-      } else {
-        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-      }
+      if constexpr (sizeof(T) == 2) v[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+      else v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const int p = row + i * DW_TH;
-      if (p < HH * HW_) store4<T>(halo + (long)p * C + q * 4, v[i]);
+      const int p = row + i * TS;
+      if (p < HH * HW_) *(raw_t*)(halo + (long)p * C + q * 4) = v[i];
     }
   }
   if (dbgw) TT[1] = wall_clock64();
   for (int i = threadIdx.x; i < 49 * Q; i += blockDim.x) *(f32x4*)(wl + i * 4) = *(const f32x4*)(dw + i * 4);
   __syncthreads();
   if (dbgw) TT[2] = wall_clock64();
-  f32x4 acc[DW_TW];
+  f32x4 acc[TS];
   {
     const f32x4 bq = *(const f32x4*)(db + q * 4);
 #pragma unroll
-    for (int k = 0; k < DW_TW; ++k) acc[k] = bq;
+    for (int k = 0; k < TS; ++k) acc[k] = bq;
   }
 #pragma unroll 1
   for (int ky = 0; ky < 7; ++ky) {
@@ -928,14 +925,14 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
     for (int kx = 0; kx < 7; ++kx) {
       const f32x4 wv = *(const f32x4*)(wl + (ky * 7 + kx) * C + q * 4);
 #pragma unroll
-      for (int k = 0; k < DW_TW; ++k)
+      for (int k = 0; k < TS; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(in[k + kx][j], wv[j], acc[k][j]);
     }
   }
   if (dbgw) TT[3] = wall_clock64();
 #pragma unroll
-  for (int k = 0; k < DW_TW; ++k) red[(row * DW_TW + k) * Q + q] = acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  for (int k = 0; k < TS; ++k) red[(row * TS + k) * Q + q] = acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
   __syncthreads();
   if (threadIdx.x < NPIX) {
     float m = 0.f;
@@ -943,12 +940,12 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
     stat[threadIdx.x] = m / (float)C;
   }
   __syncthreads();
-  float mean[DW_TW];
+  float mean[TS];
 #pragma unroll
-  for (int k = 0; k < DW_TW; ++k) {
-    mean[k] = stat[row * DW_TW + k];
+  for (int k = 0; k < TS; ++k) {
+    mean[k] = stat[row * TS + k];
     const f32x4 d = acc[k] - mean[k];
-    red[(row * DW_TW + k) * Q + q] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    red[(row * TS + k) * Q + q] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
   }
   __syncthreads();
   if (threadIdx.x < NPIX) {
@@ -962,10 +959,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_row_kernel(const T* __restrict
   const int oy = ty0 + row;
   if (oy < H) {
 #pragma unroll
-    for (int k = 0; k < DW_TW; ++k) {
+    for (int k = 0; k < TS; ++k) {
       const int ox = tx0 + k;
       if (ox >= W) continue;
-      const float rstd = stat[row * DW_TW + k];
+      const float rstd = stat[row * TS + k];
       if (uo) store4<T>(uo + n * usn + oy * ush + ox * usw + q * 4, acc[k]);
       store4<T>(y + n * ysn + oy * ysh + ox * ysw + q * 4, (acc[k] - mean[k]) * rstd * gq + bq2);
     }
@@ -990,17 +987,44 @@ static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* d
   if (!view_ok(x) || !view_ok(y) || !dw_w || !dw_b || !ln_w || !ln_b) MGDT_FAIL(MGDT_BAD_ARG, "dwconv7_ln: null/empty argument");
   if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || x->c != y->c || x->c / 4 > 256)
     MGDT_FAIL(MGDT_BAD_SHAPE, "dwconv7_ln: matching NHWC views, c%%4==0, c<=1024");
-  {   // LDS-tiled fast path: channel quads divide the block and the halo + weights fit in 64 KiB
+  {   // LDS-tiled fast path: one thread per (channel quad, tile row); tile side 8 or 10: whichever needs fewer rounds of workgroups over the
+      // chip x pixels per round (a 40x40 map: 25 tiles of 8x8 per image = 800 workgroups = two rounds at 2 per CU; 16 tiles of 10x10 = one round)
     const int Qt = x->c / 4;
-    const size_t halo_b = ((size_t)(DW_TH + 6) * (DW_TW + 6) * x->c * dtype_size(dtype) + 15) & ~(size_t)15;
-    const size_t lds_t = halo_b + (size_t)49 * x->c * 4 + (size_t)DW_TH * DW_TW * Qt * 4;
-    if (Qt <= 32 && lds_t + 256 <= 64 * 1024) {            // one thread per (channel quad, tile row)
-      const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
+    auto lds_of = [&](int ts) {
+      const size_t halo_b = ((size_t)(ts + 6) * (ts + 6) * x->c * dtype_size(dtype) + 15) & ~(size_t)15;
+      return halo_b + (size_t)49 * x->c * 4 + (size_t)ts * ts * Qt * 4 + (size_t)ts * ts * sizeof(float);
+    };
+    auto cost_of = [&](int ts) -> long {
+      const size_t l = lds_of(ts);
+      if (ts * Qt > 256 || l + 256 > (ts == 8 ? 64 : 80) * 1024) return -1;
+      const long nwg = (long)x->n * cdiv(x->h, ts) * cdiv(x->w, ts), per_cu = std::max<long>(1, std::min<long>(160 * 1024 / (long)(l + 256), 2048 / (ts * Qt)));
+      return cdiv(nwg, 256 * per_cu) * ts * ts;
+    };
+    static const int force_ts = getenv("MGDT_DW_TS") ? atoi(getenv("MGDT_DW_TS")) : 0;      // experiment knob
+    const long c8 = cost_of(8), c10 = cost_of(10);
+    const int ts = force_ts == 8 || force_ts == 10 ? force_ts : (c10 >= 0 && (c8 < 0 || c10 < c8) ? 10 : 8);
+    if (Qt <= 32 && (ts == 8 ? c8 : c10) >= 0) {
+      const int tiles = cdiv(x->h, ts) * cdiv(x->w, ts);
+      const size_t lds_t = lds_of(ts);
       static unsigned long long* dbgbuf = nullptr;
       if (getenv("MGDT_DW_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, (size_t)x->n * tiles * 6 * 8);
-      MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_row_kernel<T><<<x->n * tiles, 8 * Qt, lds_t + DW_TH * DW_TW * sizeof(float), (hipStream_t)s>>>(
-                                     (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c,
-                                     u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0, dbgbuf)));
+      static std::atomic<bool> attr10_f32{false}, attr10_bf16{false};
+      if (ts == 10) {
+        MGDT_DISPATCH_DTYPE(dtype, {
+          std::atomic<bool>& fl = sizeof(T) == 2 ? attr10_bf16 : attr10_f32;
+          if (!fl.load()) {
+            (void)hipFuncSetAttribute((const void*)dwconv7_ln_row_kernel<T, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            fl.store(true);
+          }
+          dwconv7_ln_row_kernel<T, 10><<<x->n * tiles, 10 * Qt, lds_t, (hipStream_t)s>>>(
+              (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c,
+              u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0, dbgbuf);
+        });
+      } else {
+        MGDT_DISPATCH_DTYPE(dtype, (dwconv7_ln_row_kernel<T, 8><<<x->n * tiles, 8 * Qt, lds_t, (hipStream_t)s>>>(
+                                       (const T*)x->p, x->sn, x->sh, x->sw, dw_w, dw_b, ln_w, ln_b, eps, (T*)y->p, y->sn, y->sh, y->sw, x->h, x->w, x->c,
+                                       u ? (T*)u->p : nullptr, u ? u->sn : 0, u ? u->sh : 0, u ? u->sw : 0, dbgbuf)));
+      }
       MGDT_CHECK_LAUNCH("dwconv7_ln_fwd(row)");
       if (dbgbuf) {
         const int nwg = x->n * tiles;
@@ -1014,6 +1038,7 @@ static int dwconv7_ln_impl(const mgdt_view* x, const float* dw_w, const float* d
       }
       return MGDT_OK;
     }
+    const size_t lds_t = (((size_t)(DW_TH + 6) * (DW_TW + 6) * x->c * dtype_size(dtype) + 15) & ~(size_t)15) + (size_t)49 * x->c * 4 + (size_t)DW_TH * DW_TW * Qt * 4;
     if (Qt <= 64 && lds_t <= 64 * 1024) {
       const int tiles = cdiv(x->h, DW_TH) * cdiv(x->w, DW_TW);
       const int need = cdiv(DW_TH * DW_TW, 256 / Qt);      // pixels per thread

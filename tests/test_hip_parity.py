@@ -98,6 +98,32 @@ def test_convnext_fused_mlp_matches_three_launch_chain(dim, hw):
     assert (y_fused - y32).abs().max().item() < 3e-2 * scale
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('b,c,hw', [(32, 96, (40, 40)), (3, 96, (23, 17)), (2, 64, (13, 9)), (1, 32, (7, 21)), (2, 160, (12, 10))],
+                         ids=['bench-tile10', 'odd-96', 'c64', 'c32', 'c160-tiled'])
+def test_dwconv7_layernorm_kernel_vs_torch(b, c, hw, dtype):
+    """The ConvNeXt block's first half (convnextv2.py:61-66: 7x7 depth-wise conv, channels-last LayerNorm) in one launch, every tile shape the
+    host picks (10x10 tiles for the bench map: one round of workgroups; 8x8 otherwise; the generic kernels for wide maps), against
+    F.conv2d(groups=C) + F.layer_norm in float64.  The training form also returns the conv output `u`."""
+    import torch.nn.functional as F
+    from mgdt_yolo_amd import ops
+    gen = torch.Generator().manual_seed(c + hw[0])
+    x = torch.randn(b, c, *hw, generator=gen).to(dtype)
+    w, bias = torch.randn(c, 1, 7, 7, generator=gen) * 0.2, torch.randn(c, generator=gen) * 0.1
+    lw, lb = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.1
+    u_ref = F.conv2d(x.double(), w.double(), bias.double(), 1, 3, 1, c)
+    y_ref = F.layer_norm(u_ref.permute(0, 2, 3, 1), (c,), lw.double(), lb.double(), 1e-6).permute(0, 3, 1, 2)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    w49 = w.reshape(c, 49).t().contiguous().to(DEV)
+    args = (w49, bias.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6)
+    y = ops.dwconv7_ln(xd, *args)
+    y2, u = ops.dwconv7_ln_train(xd, *args)
+    assert torch.equal(y, y2)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    assert (y.double().cpu() - y_ref).abs().max().item() < tol * max(1.0, y_ref.abs().max().item())
+    assert (u.double().cpu() - u_ref).abs().max().item() < tol * max(1.0, u_ref.abs().max().item())
+
+
 @pytest.mark.parametrize('c,n,hw', [(32, 1, (20, 24)), (64, 2, (17, 13)), (128, 2, (9, 11)), (256, 1, (6, 5)), (96, 1, (8, 8)), (192, 1, (5, 7))])
 def test_mspa_pointwise_chain_matches_three_convs(c, n, hw):
     """bf16: mgdt_pw_chain3_fwd (sp_i kept in accumulators, rounded to bf16 where the unfused chain would store them) vs three
