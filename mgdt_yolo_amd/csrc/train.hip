@@ -329,10 +329,18 @@ bool mgdt_wgrad_mfma_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_
 #define WG_SPLITS 16
 // pixel splits of the NHWC path: more of them for small weight tensors (few (co, ci, tap) blocks) so that the grid still fills the chip;
 // the partial buffer stays <= max(16 splits, 16 MiB)
+int mgdt_wgrad_bf16_groups(int cin, int cout, int k);   // wgrad_bf16.hip
 static inline int wgrad_splits(int cin, int cout, int k) {
   const long nel = (long)cin * cout * k * k;
   static const long cap = getenv("MGDT_WGRAD_SPLITS") ? atol(getenv("MGDT_WGRAD_SPLITS")) : 512;     // experiment knob
-  return (int)std::max<long>(WG_SPLITS, std::min<long>(cap, (4L << 20) / std::max<long>(nel, 1)));
+  static const long budget = getenv("MGDT_WGRAD_PARTIAL_ELEMS") ? atol(getenv("MGDT_WGRAD_PARTIAL_ELEMS")) : (4L << 20);     // experiment knob
+  long ns = std::max<long>(WG_SPLITS, std::min<long>(cap, budget / std::max<long>(nel, 1)));
+  // big channel tiles leave few (cout, cin) groups: up to twice the splits so that groups x splits reaches ~2 workgroups per CU (the 64->96 3x3 head
+  // convolution ran 216 workgroups of 4 waves on 256 CUs)
+  static const long fill = getenv("MGDT_WGRAD_FILL") ? atol(getenv("MGDT_WGRAD_FILL")) : 448;     // experiment knob, 0 = off
+  const int g = fill ? mgdt_wgrad_bf16_groups(cin, cout, k) : 0;
+  if (g > 0 && g * ns < fill) ns = std::min<long>({cap, 2 * ns, (fill + g - 1) / g});
+  return (int)ns;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(const mgdt_view x, const mgdt_view x2, const mgdt_view dy, int KS, int stride,

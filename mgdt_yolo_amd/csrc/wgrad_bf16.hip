@@ -232,6 +232,14 @@ static void wb_launch(const WbArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   conv_wgrad_bf16_kernel<AT, NCW><<<grid, 256, lds, st>>>(a);
 }
 
+// (cout tile, cin tile) groups of the configuration wb_pick chooses at stride 1: train.hip sizes the pixel splits so that groups x splits fills the chip
+int mgdt_wgrad_bf16_groups(int cin, int cout, int k) {
+  if ((k != 1 && k != 3) || cin % 4 || cout % 8) return 0;
+  const int ncob = cdiv(cout, 16), ncib = cdiv(cin, 16);
+  const WbCfg cfg = wb_pick(ncob, ncib, k * k, 1, k);
+  return cfg.AT ? cdiv(ncob, cfg.AT * cfg.WA) * cdiv(ncib, cfg.BT) : 0;
+}
+
 // Called by mgdt_conv_wgrad (train.hip) for bf16 NHWC inputs; partial: fp32 [nsplit][cout][cin][k*k].  false -> the caller keeps the fp32 MFMA kernel.
 bool mgdt_wgrad_bf16_launch(const mgdt_view* x, const mgdt_view* x2, const mgdt_view* dy, int k, int stride, float* partial, int nsplit, hipStream_t st) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (k == 1 && stride != 1) || x->sc != 1 || dy->sc != 1) return false;
