@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'fp8': 5000.0}   # fp8: the dtype's dense peak (block-scaled K=128 form); the non-scaled 16x16x32 e4m3 form used here runs at the bf16 rate
 N_RESIDENT = 8                 # resident input batches cycled through (8 x 78.6 MB bf16 = 629 MB > the 256 MiB Infinity Cache)
 
 
@@ -43,7 +43,9 @@ def parse():
     ap.add_argument('--input', choices=['model', 'f32', 'u8'], default='model',
                     help="dtype of the resident image batch: 'model' = the compute dtype, what the reference's predictor hands its model "
                          "(img.half() / 255, engine/predictor.py:128-129); 'u8' = raw uint8, /255 fused into the stem kernel")
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'],
+                    help="fp8 (BASELINE configs[4], inference only): e4m3 operands on the implicit-GEMM convolutions (model.quantize_fp8 on one "
+                         "calibration batch), bf16 activations in HBM and bf16 block kernels")
     ap.add_argument('--model', default='mspa_c2f_gd_yolov8')
     ap.add_argument('--scale', default='n')
     ap.add_argument('--no-graph', action='store_true')
@@ -165,7 +167,7 @@ def roofline_of(prof_rows, reps, step_ms, graph, args):
     else:
         ach = bytes_l / avg_s / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
-    kern = {'conv2d_fwd': 'conv_igemm_kernel (+ conv3x3_lds_kernel for the 64->96 Detect-branch 3x3)', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
+    kern = {'conv2d_fp8_fwd': 'conv_igemm_kernel<.., Q8> (e4m3 MFMA)', 'conv2d_fwd': 'conv_igemm_kernel (+ conv3x3_lds_kernel for the 64->96 Detect-branch 3x3)', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
             'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel', 'csp_block_fwd': 'csp_block_kernel'}.get(name, name)
     traffic, tsrc, tat = None, None, None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_pmc.sh), corrected
@@ -219,7 +221,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    if args.dtype == 'fp8' and args.mode != 'infer':
+        raise SystemExit('bench.py: --dtype fp8 is an inference configuration (BASELINE configs[4])')
+    tdt = torch.float32 if args.dtype == 'f32' else torch.bfloat16
     graph_used = False
 
     if args.mode == 'train':
@@ -267,6 +271,10 @@ def main():
             elif args.input == 'model':
                 x = x.to(tdt)
             xs.append(x)
+        fp8_note = ''
+        if args.dtype == 'fp8':    # calibrate on a batch that is not one of the timed ones
+            table = model.quantize_fp8(seeded_images(args.batch, args.imgsz, args.imgsz, seed=parallel.shard_seed(9000, rank)).to(dev).to(tdt))
+            fp8_note = f'; fp8: {len(table)} implicit-GEMM convolutions on e4m3 MFMAs (per-tensor activation / per-channel weight scales), bf16 elsewhere; BASELINE configs[4]'
 
         def step(x):
             y, _ = model(x)
@@ -308,7 +316,7 @@ def main():
                 it[0] += 1
         x_desc = f'{str(xs[0].dtype).replace("torch.", "")} NCHW images, {R} different batches resident in HBM ({R * xs[0].numel() * xs[0].element_size() / 2**20:.0f} MiB) cycled'
         workload = (f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, batch {args.batch}/GPU: '
-                    f'forward + decode + NMS(conf 0.25, iou 0.7), ' + ('hipGraph replay' if graph_used else 'eager launches'))
+                    f'forward + decode + NMS(conf 0.25, iou 0.7), ' + ('hipGraph replay' if graph_used else 'eager launches') + fp8_note)
         metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, detection forward + NMS (whole job: {world} GPU(s))'
         parallelism = f'replicas x{world} (batch-sharded, no data-path collective)'
 

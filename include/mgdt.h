@@ -73,6 +73,21 @@ int mgdt_conv_pack_batch(const mgdt_pack_desc* descs, int n, mgdt_stream s);
 int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                     const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
                     const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s);
+/* ---- fp8 (OCP e4m3fn) variant of the fused convolution - BASELINE configs[4] ("fp8 inference: CDNA4 fp8-MFMA implicit-GEMM convs"; the
+ * reference has no fp8 path: yolo/engine/trainer.py:223 is fp16 autocast only, so the numerics are checked against an e4m3 emulation of
+ * nn/modules/conv.py:25-42 and, end to end, against the fp32 fixtures with a stated tolerance).
+ * W8A8, fp32 accumulation: activations stay bf16 in HBM and are converted in registers, x_q = e4m3(clamp(x * x_qscale, +-448)) (per-tensor
+ * x_qscale, calibrated by the caller); weights are packed once as e4m3(w' / w_scale[co]) with w' the BN-folded weight and
+ * w_scale[co] = max|w'[co]| / 448; y = act(acc * oscale[co] + bias[co]) [+ r1] [+ r2], oscale[co] = w_scale[co] / x_qscale.
+ * mgdt_conv_pack_fp8 writes the panel (mgdt_conv_packed_bytes_fp8), bias_out[cout_pad] and oscale_out[cout_pad] (cout rounded up to 16);
+ * mgdt_conv2d_fp8_fwd takes the same views / fused extras as mgdt_conv2d_fwd with dtype MGDT_BF16.  cin % 8 == 0, cout % 4 == 0, k in {1, 3}. */
+size_t mgdt_conv_packed_bytes_fp8(int cin, int cout, int k);
+int mgdt_conv_pack_fp8(const float* w_oihw, const float* conv_bias, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                       const float* bn_var, float bn_eps, int cin, int cout, int k, float x_qscale, void* packed_out, float* bias_out,
+                       float* oscale_out, mgdt_stream s);
+int mgdt_conv2d_fp8_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift, const void* packed_w,
+                        const float* bias, const float* oscale, float x_qscale, int k, int stride, int act, const mgdt_view* r1,
+                        const mgdt_view* r2, const mgdt_view* y, mgdt_stream s);
 /* One phase (py, px) = phase >> 1, phase & 1 of the data gradient of a stride-2 3x3 convolution: dx[:, 2i+py, 2j+px] as a stride-1 convolution of dy
  * whose K holds only the taps that phase uses (packed by mgdt_conv_pack_dgrad(phase)); replaces the four 9-tap convolutions over mostly-zero weights.
  * Reference: the autograd of the stride-2 nn.Conv2d layers (backbone rows 0, 1, 3, 5, 7 of models/v8/*.yaml). */

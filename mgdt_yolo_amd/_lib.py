@@ -39,6 +39,9 @@ PROTOTYPES = {
     'mgdt_conv_packed_bytes': (_sz, [_i, _i, _i, _i]),
     'mgdt_conv_pack': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mgdt_conv2d_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _i, _i, VP, VP, VP, _i, _vp]),
+    'mgdt_conv_packed_bytes_fp8': (_sz, [_i, _i, _i]),
+    'mgdt_conv_pack_fp8': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'mgdt_conv2d_fp8_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, VP, VP, VP, _vp]),
     'mgdt_conv_pack_batch': (_i, [_vp, _i, _vp]),
     'mgdt_conv2d_phase_fwd': (_i, [VP, _vp, _vp, _i, VP, VP, VP, _i, _vp]),
     'mgdt_conv_wgrad_splits': (_i, [_i, _i, _i]),

@@ -157,6 +157,96 @@ extern "C" int mgdt_conv_pack_dgrad(const float* w, int cin, int cout, int k, in
   return MGDT_OK;
 }
 
+// ---- fp8 (e4m3) panels - BASELINE configs[4].  Per output channel: BN-folded weights w' = w * gamma / sqrt(var + eps), w_scale = max|w'| / 448,
+// panel bytes = e4m3(w' / w_scale) in the bf16 panel's fragment order (8 K values per lane: 512-byte blocks), oscale = w_scale / x_qscale
+// (1 for the padding channels), bias_out as mgdt_conv_pack.  One workgroup per output channel computes the scale; the packing pass is elementwise.
+__global__ void q8_wscale_kernel(const float* __restrict__ w, FoldArgs fa, int per_cout, float xq, float* __restrict__ wscale, float* __restrict__ oscale) {
+  const int c = blockIdx.x;
+  __shared__ float red[256];
+  float m = 0.f;
+  if (c < fa.cout_real)
+    for (int i = threadIdx.x; i < per_cout; i += blockDim.x) m = fmaxf(m, fabsf(w[(long)c * per_cout + i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float bo = 0.f, ws = 1.f;
+    if (c < fa.cout_real) {
+      float fold = 1.f;
+      if (fa.g) {
+        fold = fa.g[c] / sqrtf(fa.eps + fa.var[c]);
+        bo = fa.b[c] - fa.g[c] * fa.mu[c] / sqrtf(fa.var[c] + fa.eps);
+        if (fa.cb) bo += fold * fa.cb[c];
+      } else if (fa.cb) {
+        bo = fa.cb[c];
+      }
+      const float amax = red[0] * fabsf(fold);
+      ws = amax > 0.f ? amax / 448.f : 1.f;
+    }
+    wscale[c] = ws;
+    oscale[c] = ws / xq;
+    fa.bias_out[c] = bo;
+  }
+}
+__global__ void pack_q8_kernel(const float* __restrict__ w, FoldArgs fa, const float* __restrict__ wscale, int Cin, int Cout, int KS, int CP, int nchunks,
+                               int NTtot, long* __restrict__ out) {
+  typedef __attribute__((ext_vector_type(2))) int i32x2;
+  const long total = (long)nchunks * NTtot * 64;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(t % 64);
+    const int nb = (int)((t / 64) % NTtot), kc = (int)(t / 64 / NTtot);
+    const int r = lane & 15, g = lane >> 4;
+    const int p = kc * 4 + g, tap = p / CP, cp = p % CP, cout = nb * 16 + r;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cin = cp * 8 + j;
+      float q = 0.f;
+      if (tap < KS * KS && cin < Cin && cout < Cout) {
+        q = w[(((long)cout * Cin + cin) * KS + tap / KS) * KS + tap % KS];
+        if (fa.g) q *= fa.g[cout] / sqrtf(fa.eps + fa.var[cout]);
+        q = __builtin_amdgcn_fmed3f(q / wscale[cout], -448.f, 448.f);
+      }
+      v[j] = q;
+    }
+    i32x2 o = {0, 0};
+    o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], o[0], false);
+    o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], o[0], true);
+    o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], o[1], false);
+    o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], o[1], true);
+    out[t] = __builtin_bit_cast(long, o);
+  }
+}
+
+extern "C" size_t mgdt_conv_packed_bytes_fp8(int cin, int cout, int k) {
+  int CP, nchunks, NTtot;
+  conv_geometry(cin, cout, k, MGDT_BF16, &CP, &nchunks, &NTtot);
+  return (size_t)nchunks * NTtot * 512 + (size_t)NTtot * 16 * sizeof(float);   // + the per-channel weight scales (scratch of the packing pass)
+}
+
+extern "C" int mgdt_conv_pack_fp8(const float* w, const float* cb, const float* g, const float* b, const float* mu, const float* var, float eps,
+                                  int cin, int cout, int k, float x_qscale, void* packed, float* bias_out, float* oscale_out, mgdt_stream s) {
+  if (!w || !packed || !bias_out || !oscale_out) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_fp8: null pointer");
+  if ((g != nullptr) != (b != nullptr) || (g != nullptr) != (mu != nullptr) || (g != nullptr) != (var != nullptr))
+    MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_fp8: BN arguments must be all present or all NULL");
+  if (!(x_qscale > 0.f) || !(x_qscale < 3.0e38f)) MGDT_FAIL(MGDT_BAD_ARG, "conv_pack_fp8: x_qscale must be a positive finite number");
+  if (cin % 8 || cout % 4 || (k != 1 && k != 3)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv_pack_fp8: cin=%d must be a multiple of 8, cout=%d of 4, k=%d 1 or 3", cin, cout, k);
+  int CP, nchunks, NTtot;
+  conv_geometry(cin, cout, k, MGDT_BF16, &CP, &nchunks, &NTtot);
+  hipStream_t st = (hipStream_t)s;
+  float* wscale = (float*)((char*)packed + (size_t)nchunks * NTtot * 512);
+  const int cpad = NTtot * 16;
+  const FoldArgs fa{cb, g, b, mu, var, eps, cout, cpad, bias_out};
+  q8_wscale_kernel<<<cpad, 256, 0, st>>>(w, fa, cin * k * k, x_qscale, wscale, oscale_out);
+  const long total = (long)nchunks * NTtot * 64;
+  pack_q8_kernel<<<(int)std::min<long>((total + 255) / 256, 4096), 256, 0, st>>>(w, fa, wscale, cin, cout, k, CP, nchunks, NTtot, (long*)packed);
+  MGDT_CHECK_LAUNCH("conv_pack_fp8");
+  return MGDT_OK;
+}
+
 // ---- batched re-pack: after an optimizer step every live packed panel of a training model is refreshed in a handful of launches instead of one (two) per
 // convolution (131 launches of ~4.5 us per step for the MSPA-GD n model).  One descriptor = one mgdt_conv_pack / mgdt_conv_pack_dgrad call.
 struct PackJob { const float* w; FoldArgs fa; int Cin, Cout, KS, CP, nchunks, NTtot, dgrad; void* out; };
@@ -249,21 +339,30 @@ extern "C" int mgdt_conv_pack_batch(const mgdt_pack_desc* d, int n, mgdt_stream 
 
 bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st);
 
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, bool Q8>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st);   // defined in conv_igemm_inst_*.hip
 
 template <typename T>
 static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, int threads, size_t lds, hipStream_t st) {
 #define CASE(nt, mt) \
-  if (NT == nt && MT == mt) return launch_igemm<T, nt, mt>(a, gx, gy, threads, lds, st);
+  if (NT == nt && MT == mt) return launch_igemm<T, nt, mt, false>(a, gx, gy, threads, lds, st);
   CASE(1, 2) CASE(1, 4) CASE(1, 8) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
 #undef CASE
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: no kernel for NT=%d MT=%d", NT, MT);
 }
 
+static int dispatch_igemm_q8(const ConvArgs& a, int NT, int gx, int gy, int threads, size_t lds, hipStream_t st) {
+#define CASE(nt) \
+  if (NT == nt) return launch_igemm<bf16, nt, 2, true>(a, gx, gy, threads, lds, st);
+  CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(8)
+#undef CASE
+  MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d_fp8: no kernel for NT=%d", NT);
+}
+
 static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                            const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
-                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s);
+                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s,
+                           const float* q8_oscale = nullptr, float q8_xq = 1.f);
 extern "C" int mgdt_conv2d_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                                const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
                                const mgdt_view* r2, const mgdt_view* y, int dtype, mgdt_stream s) {
@@ -276,9 +375,20 @@ extern "C" int mgdt_conv2d_phase_fwd(const mgdt_view* x, const void* packed_w, c
   if (phase < 0 || phase > 3) MGDT_FAIL(MGDT_BAD_ARG, "conv2d_phase: phase %d", phase);
   return conv2d_fwd_impl(x, nullptr, nullptr, nullptr, packed_w, bias, 3, 1, MGDT_ACT_NONE, r1, r2, y, dtype, 2 + phase, s);
 }
+// fp8 (e4m3) variant - BASELINE configs[4]: bf16 views, panel from mgdt_conv_pack_fp8 (same x_qscale), fp8 MFMAs, fp32 accumulation
+extern "C" int mgdt_conv2d_fp8_fwd(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
+                                   const void* packed_w, const float* bias, const float* oscale, float x_qscale, int k, int stride, int act,
+                                   const mgdt_view* r1, const mgdt_view* r2, const mgdt_view* y, mgdt_stream s) {
+  if (!oscale) MGDT_FAIL(MGDT_BAD_ARG, "conv2d_fp8: null oscale");
+  if (!(x_qscale > 0.f) || !(x_qscale < 3.0e38f)) MGDT_FAIL(MGDT_BAD_ARG, "conv2d_fp8: x_qscale must be a positive finite number");
+  return conv2d_fwd_impl(x, x2, in_scale, in_shift, packed_w, bias, k, stride, act, r1, r2, y, MGDT_BF16, 0, s, oscale, x_qscale);
+}
 static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float* in_scale, const float* in_shift,
                            const void* packed_w, const float* bias, int k, int stride, int act, const mgdt_view* r1,
-                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s) {
+                           const mgdt_view* r2, const mgdt_view* y, int dtype, int tapmode, mgdt_stream s,
+                           const float* q8_oscale, float q8_xq) {
+  const bool q8 = q8_oscale != nullptr;
+  const int WB = q8 ? 512 : 1024;
   if (!view_ok(x) || !view_ok(y) || !packed_w || !bias) MGDT_FAIL(MGDT_BAD_ARG, "conv2d: null/empty view or weights");
   if (dtype != MGDT_F32 && dtype != MGDT_BF16) MGDT_FAIL(MGDT_BAD_DTYPE, "conv2d: dtype %d", dtype);
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2)) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: k=%d stride=%d unsupported", k, stride);
@@ -318,6 +428,7 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   a.y = (char*)yp;
   a.in_scale = in_scale; a.in_shift = in_shift;
   a.wpk = (const char*)packed_w; a.bias = bias;
+  a.oscale = q8_oscale; a.xq = q8_xq;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Ho = Ho; a.Wo = Wo; a.Cout = y->c;
   a.KS = k; a.stride = stride; a.pad = pad; a.act = act;
   a.ntaps = tapmode >= 2 ? phase_ntaps(tapmode) : k * k;
@@ -328,7 +439,7 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   a.M = (int)M; a.HoWo = Ho * Wo;
   a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
   // plain 3x3 stride-1 bf16 layers with 32-80 input channels on large maps: the LDS-staged kernel (conv3x3_lds.hip)
-  if (tapmode == 0 && dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
+  if (!q8 && tapmode == 0 && dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
       mgdt_conv3x3_lds_launch(x, y, packed_w, bias, act, a.CP, a.nchunks, a.NTtot, (hipStream_t)s)) {
     MGDT_CHECK_LAUNCH("conv2d(3x3 lds)");
     return MGDT_OK;
@@ -340,9 +451,9 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   { const char* e = getenv("MGDT_CONV_PANEL_KIB"); if (e) LDS_PANEL_KIB = atoi(e); }   // experiment knob (not part of the ABI)
   int NT = 1;
   for (int c : {8, 6, 5, 4, 3, 2, 1})
-    if (a.NTtot % c == 0 && a.nchunks * c <= LDS_PANEL_KIB) { NT = c; break; }
+    if (a.NTtot % c == 0 && (long)a.nchunks * c * WB <= LDS_PANEL_KIB * 1024L) { NT = c; break; }
   int MT = 2;   // MT=2 with depth-4 prefetch measured faster than MT=4 on every wide layer of the target nets
-  if (NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e ? atoi(e) : 2; }
+  if (!q8 && NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e ? atoi(e) : 2; }
   int waves = 8;
   auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
   // (4-wave workgroups for small maps were tried: 8 waves measured faster on the whole net - fewer, fuller workgroups stage the weight panel less often)
@@ -358,14 +469,15 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   a.numTiles = cdiv(M, 16 * waves * MT);
   a.T8 = cdiv(a.numTiles, 8);
   a.tab_bytes = (a.nchunks + 3) / 4 * 4 * 4 * 16;   // uint4 per piece, padded to a multiple of 4 chunks (>= nchp in the kernel)
-  size_t panel = (size_t)a.nchunks * NT * 1024;
+  size_t panel = (size_t)a.nchunks * NT * WB;
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
-  size_t lds = a.tab_bytes + (size_t)NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * 1024;
+  size_t lds = a.tab_bytes + (size_t)(q8 ? 2 : 1) * NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * WB;
   int gcap = waves == 8 ? 512 : 1024;
   { const char* e = getenv("MGDT_CONV_GCAP"); if (e) gcap = atoi(e); }
   int gx = std::min(8 * a.T8, gcap), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
+  if (q8) return dispatch_igemm_q8(a, NT, gx, gy, waves * 64, lds, st);
   if (dtype == MGDT_F32) return dispatch_igemm<float>(a, NT, MT, gx, gy, waves * 64, lds, st);
   return dispatch_igemm<bf16>(a, NT, MT, gx, gy, waves * 64, lds, st);
 }

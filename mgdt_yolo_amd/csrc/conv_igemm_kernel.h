@@ -25,6 +25,7 @@ struct ConvArgs {   // all strides / offsets in BYTES and < 2 GiB (host-checked)
   FastDiv fd_howo, fd_wo;
   uint32_t x_bytes, x2_bytes, y_bytes, r1_bytes, r2_bytes;   // addressable extents of the views (buffer descriptor ranges)
   int ntaps; unsigned long long taplist;                     // K enumerates these taps only (4 bits each; all KS*KS by default): the phase convs of a stride-2 data gradient use 1, 2 or 4 of the 9
+  const float* oscale; float xq;                             // fp8 (Q8) kernels only: per-output-channel de-quantisation factor w_scale[co] / xq, activation multiplier before the e4m3 conversion
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -87,6 +88,30 @@ __device__ __forceinline__ f32x4 mma(bf16x8 w, bf16x8 p, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, p, acc, 0, 0, 0);
 }
 
+// fp8 (OCP e4m3fn on gfx950) operands: 8 values per lane in one 64-bit register, same (row, 8g..8g+7) K layout as the bf16 16x16x32 form,
+// same accumulator layout, the bf16 form's rate (MI355X_MICROARCH.md: non-scaled fp8 = bf16 cycles).
+__device__ __forceinline__ f32x4 mma_q8(long w, long p, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w, p, acc, 0, 0, 0);
+}
+// 8 bf16 activations -> 8 e4m3 bytes: x * xq, clamped to the finite e4m3 range (the conversion itself does not saturate), round-to-nearest-even
+__device__ __forceinline__ long quant8(bf16x8 v, float xq) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(2))) int i32x2;
+  const u32x4 d = __builtin_bit_cast(u32x4, v);
+  auto cv = [&](unsigned int w, float& lo, float& hi) __attribute__((always_inline)) {
+    lo = __builtin_amdgcn_fmed3f(__uint_as_float(w << 16) * xq, -448.f, 448.f);
+    hi = __builtin_amdgcn_fmed3f(__uint_as_float(w & 0xffff0000u) * xq, -448.f, 448.f);
+  };
+  float l0, h0, l1, h1, l2, h2, l3, h3;
+  cv(d[0], l0, h0); cv(d[1], l1, h1); cv(d[2], l2, h2); cv(d[3], l3, h3);
+  i32x2 o = {0, 0};
+  o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(l0, h0, o[0], false);
+  o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(l1, h1, o[0], true);
+  o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(l2, h2, o[1], false);
+  o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(l3, h3, o[1], true);
+  return __builtin_bit_cast(long, o);
+}
+
 // ------------------------------------------------------------------------------------------------ main kernel
 // blockDim.x = 64 * nwaves (4, 8 or 16 waves); a workgroup covers nwaves*MT*16 output pixels x NT*16 output channels per
 // tile and is PERSISTENT over tiles blockIdx.x + j*gridDim.x.  Per tile the K-chunks are padded to a multiple of D steps so
@@ -98,16 +123,21 @@ __device__ __forceinline__ f32x4 mma(bf16x8 w, bf16x8 p, f32x4 acc) {
 struct TileState { int xo; uint32_t vm; int yo, x2o, r1o, r2o, pn; };   // byte offsets; MGDT_OOB = "no such pixel"
 #define MGDT_OOB ((int)0x80000000)   // >= every view extent, and stays out of range after a (small) channel offset is added
 
-template <typename T, int NT, int MT, int D, bool EXTRA, bool MULTI>
+// Q8 (T = bf16 only): activations stay bf16 in HBM and are converted to e4m3 in registers (quant8), the weight panel holds e4m3 bytes
+// (512-byte blocks), the accumulators are multiplied by oscale[cout] in the epilogue - BASELINE configs[4].
+template <typename T, int NT, int MT, int D, bool EXTRA, bool MULTI, bool Q8 = false>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   typedef typename Piece<T>::frag frag;
+  static_assert(!Q8 || std::is_same<T, bf16>::value, "the fp8 kernels read bf16 activations");
+  constexpr int WB = Q8 ? 512 : 1024;  // bytes of one [chunk][16 couts] weight block
   constexpr int PE = Piece<T>::PE;
   constexpr int L = D - 1;             // look-ahead in (padded) steps
   constexpr int SZ = (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ptab = (uint4*)smem;          // per 16-byte K piece: {byte offset of (tap, channel) in the x view, tap, byte offset in the x2 view, channel}
   float* blds = (float*)(smem + a.tab_bytes);       // this workgroup's NT*16 bias values (accumulators start from them)
-  char* wlds = smem + a.tab_bytes + NT * 16 * sizeof(float);
+  float* olds = blds + NT * 16;                     // Q8: the matching de-quantisation factors
+  char* wlds = smem + a.tab_bytes + (Q8 ? 2 : 1) * NT * 16 * sizeof(float);
 
   const int nthr = blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,18 +158,27 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     }
     ptab[p] = e;
   }
-  if (tid < NT * 16) blds[tid] = a.bias[blockIdx.y * NT * 16 + tid];
+  if (tid < NT * 16) {
+    if constexpr (Q8) {   // accumulators start from bias / oscale so that the epilogue's one multiply restores the bias
+      const float os = a.oscale[blockIdx.y * NT * 16 + tid];
+      olds[tid] = os;
+      blds[tid] = a.bias[blockIdx.y * NT * 16 + tid] / os;
+    } else {
+      blds[tid] = a.bias[blockIdx.y * NT * 16 + tid];
+    }
+  }
   __syncthreads();
 
   auto stage = [&](int seg) __attribute__((always_inline)) {
     const int c0 = seg * a.seg_chunks;
     const int nc = min(a.seg_chunks, a.nchunks - c0);
-    const int nblk = nc * NT;  // 1 KiB blocks
-    for (int i = tid; i < nblk * 64; i += nthr) {
-      int blk = i >> 6, l = i & 63;
+    const int nblk = nc * NT;  // WB-byte blocks
+    constexpr int V = WB / 16;
+    for (int i = tid; i < nblk * V; i += nthr) {
+      int blk = i / V, l = i % V;
       int kc = blk / NT, nt = blk % NT;
-      const uint4* src = (const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * 1024) + l;
-      ((uint4*)(wlds + (long)blk * 1024))[l] = *src;
+      const uint4* src = (const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * WB) + l;
+      ((uint4*)(wlds + (long)blk * WB))[l] = *src;
     }
   };
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -232,11 +271,23 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
   auto compute = [&](const char* wp, const frag(&P)[MT]) __attribute__((always_inline)) {   // wp: this lane's slot of the chunk's weight blocks
+    if constexpr (Q8) {
+      long Pq[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const frag Wf = *(const frag*)(wp + nt * 1024);
+      for (int mt = 0; mt < MT; ++mt) Pq[mt] = quant8(P[mt], a.xq);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma(Wf, P[mt], acc[nt][mt]);
+      for (int nt = 0; nt < NT; ++nt) {
+        const long Wq = *(const long*)(wp + nt * WB);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma_q8(Wq, Pq[mt], acc[nt][mt]);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const frag Wf = *(const frag*)(wp + nt * WB);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mma(Wf, P[mt], acc[nt][mt]);
+      }
     }
   };
   // lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r); stores / residual loads go through bounds-checked descriptors, so
@@ -250,6 +301,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
         const int cob = ((nb0 + nt) * 16 + 4 * g) * SZ;
         const int dead = (ragged && cob >= a.Cout * SZ) ? MGDT_OOB : 0;
         f32x4 v = acc[nt][mt];
+        if constexpr (Q8) v *= *(const f32x4*)(olds + nt * 16 + 4 * g);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = actf(v[j]);
         if (a.r1) v += bload4<T>(r1rs, (uint32_t)(S[mt].r1o | dead) + cob);
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   if constexpr (L > 1) load_chunk(tab_g + 4, cur, P[1]);
   if constexpr (L > 2) load_chunk(tab_g + 8, cur, P[2]);
   if (!MULTI) { stage(0); __syncthreads(); }
-  const char* const wlane = wlds + lane * 16;
+  const char* const wlane = wlds + lane * (WB / 64);
   constexpr bool multi = MULTI;   // weight panel staged in K segments (only when even one cout block does not fit in LDS)
 
   for (; tile < 8 * a.T8; tile += gridDim.x) {
@@ -292,7 +344,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
       tp += 4;
       if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
       compute(wp, P[d]);
-      wp += NT * 1024;
+      wp += NT * WB;
       if (multi && ++kl == a.seg_chunks) kl = 0;
     };
     int j0 = 0;
@@ -311,7 +363,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
       if (j < a.nchunks) {
         if (multi && kl == 0) { __syncthreads(); stage(j / a.seg_chunks); __syncthreads(); wp = wlane; }
         compute(wp, P[d]);
-        wp += NT * 1024;
+        wp += NT * WB;
         if (multi && ++kl == a.seg_chunks) kl = 0;
       }
     };
@@ -324,14 +376,14 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, bool Q8 = false>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st) {
   static std::atomic<bool> attr_set{false};  // idempotent; racing setters write the same value
   constexpr bool M1 = NT == 1;   // the segmented-panel variant exists for NT == 1 only (host never asks for it otherwise)
-  const void* ks[8] = {(const void*)conv_igemm_kernel<T, NT, MT, 2, false, false>, (const void*)conv_igemm_kernel<T, NT, MT, 4, false, false>,
-                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, false>,  (const void*)conv_igemm_kernel<T, NT, MT, 4, true, false>,
-                       (const void*)conv_igemm_kernel<T, NT, MT, 2, false, M1>,    (const void*)conv_igemm_kernel<T, NT, MT, 4, false, M1>,
-                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, M1>,     (const void*)conv_igemm_kernel<T, NT, MT, 4, true, M1>};
+  const void* ks[8] = {(const void*)conv_igemm_kernel<T, NT, MT, 2, false, false, Q8>, (const void*)conv_igemm_kernel<T, NT, MT, 4, false, false, Q8>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, false, Q8>,  (const void*)conv_igemm_kernel<T, NT, MT, 4, true, false, Q8>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, false, M1, Q8>,    (const void*)conv_igemm_kernel<T, NT, MT, 4, false, M1, Q8>,
+                       (const void*)conv_igemm_kernel<T, NT, MT, 2, true, M1, Q8>,     (const void*)conv_igemm_kernel<T, NT, MT, 4, true, M1, Q8>};
   if (!attr_set) {
     for (const void* k : ks) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -350,3 +402,4 @@ int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hip
 
 
 #define MGDT_IGEMM_INSTANTIATE(T, nt) template int launch_igemm<T, nt, 2>(const ConvArgs&, int, int, int, size_t, hipStream_t);
+#define MGDT_IGEMM_INSTANTIATE_Q8(nt) template int launch_igemm<bf16, nt, 2, true>(const ConvArgs&, int, int, int, size_t, hipStream_t);

@@ -381,7 +381,7 @@ class InjectionMultiSum_Auto_pool(HipModule):
         self.global_act = Conv(global_inp[self.flag], oup, 1, act=False)
         self.act = h_sigmoid()
 
-    def _merged_global(self, g):
+    def _merged_global(self, g, xq=None):
         """PackedConv of cat(global_act, global_embedding) along cout, or None when they are not two plain 1x1 Conv+BN(no act) layers."""
         a, b = self.global_act, self.global_embedding
         ok = all(hasattr(m, 'bn') and act_code(m.act) == ops.ACT_NONE and m.conv.kernel_size == (1, 1) and m.conv.groups == 1 and m.conv.bias is None
@@ -392,9 +392,10 @@ class InjectionMultiSum_Auto_pool(HipModule):
             return None
         tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
         cat = lambda fn: torch.cat([fn(a).detach().float(), fn(b).detach().float()])
-        return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(
-            cat(lambda m: m.conv.weight), None,
-            (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps), 1, dt))
+        bn = lambda: (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        if xq is not None:      # the e4m3 panel of the same merged convolution (quantize_fp8)
+            return self._cached(('gaf', 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), None, bn(), 1, xq))
+        return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), None, bn(), 1, dt))
 
     def forward(self, x):
         x_l, x_g = x
@@ -404,7 +405,8 @@ class InjectionMultiSum_Auto_pool(HipModule):
         f = (lambda m: m.train_fwd) if train else (lambda m: m.run)
         pk2 = None if train else self._merged_global(g)
         if pk2 is not None:                                 # global_act and global_embedding read the same g: one launch, two channel ranges
-            gaf = ops.conv2d(g, pk2, 1, ops.ACT_NONE)
+            xq = self.q8_site(('gaf',), g) if pk2.dtype == torch.bfloat16 else None
+            gaf = ops.conv2d(g, pk2, 1, ops.ACT_NONE) if xq is None else ops.conv2d_fp8(g, self._merged_global(g, xq), 1, ops.ACT_NONE)
             oc = self.global_act.conv.out_channels
             ga, gf = gaf[:, :oc], gaf[:, oc:]
         else:

@@ -53,6 +53,16 @@ class HipModule(nn.Module):
             cache[key] = hit
         return hit[1]
 
+    def q8_site(self, key, x, x2=None):
+        """fp8 bookkeeping of one implicit-GEMM convolution site of this module (`key` None: the module's own conv; merged panels name theirs).
+        While BaseModel.quantize_fp8() calibrates: records the largest |input| the site sees.  Returns the site's activation multiplier, or None
+        when the site runs in bf16."""
+        if ops.Q8_CALIB is not None:
+            xe = x if x2 is None else x.float() + x2.float()
+            ops.Q8_CALIB[(self, key)] = max(ops.Q8_CALIB.get((self, key), 0.0), float(xe.abs().max()))
+        q = self.__dict__.get('_q8')
+        return None if q is None else q.get(key)
+
     @staticmethod
     def _no_train_bn(m):
         if m.training:
@@ -96,6 +106,16 @@ class Conv(HipModule):
             return ops.PackedConv(self.conv.weight, self.conv.bias, bn, k, dtype, direct=direct, groups=self.conv.groups)
         return self._cached((dtype, direct), tens, build)
 
+    def packed_fp8(self, xq):
+        has_bn = hasattr(self, 'bn')
+        tens = [self.conv.weight, self.conv.bias] + ([self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var] if has_bn else [])
+        k, _ = self._geometry()
+
+        def build():
+            bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps) if has_bn else None
+            return ops.PackedConvFp8(self.conv.weight, self.conv.bias, bn, k, xq)
+        return self._cached(('fp8', float(xq)), tens, build)
+
     # -- compute ----------------------------------------------------------------------------------------
     def run(self, x, out=None, x2=None, r1=None, r2=None, in_scale=None, in_shift=None):
         if hasattr(self, 'bn'):
@@ -103,6 +123,10 @@ class Conv(HipModule):
         k, s = self._geometry()
         dt = self.out_dtype(x) if out is None else out.dtype
         mfma = ops.conv_can_mfma(x, self.conv.in_channels, self.conv.out_channels, k, s, self.conv.groups, dt)
+        if mfma and dt == torch.bfloat16:
+            xq = self.q8_site(None, x, x2)
+            if xq is not None:                  # fp8 inference (BASELINE configs[4]): e4m3 operands, per-tensor activation / per-channel weight scales
+                return ops.conv2d_fp8(x, self.packed_fp8(xq), s, act_code(self.act), out=out, x2=x2, r1=r1, r2=r2, in_scale=in_scale, in_shift=in_shift)
         pk = self.packed(dt, direct=not mfma)
         return ops.conv2d(x, pk, s, act_code(self.act), out=out, x2=x2, r1=r1, r2=r2, in_scale=in_scale, in_shift=in_shift)
 

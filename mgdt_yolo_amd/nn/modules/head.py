@@ -79,7 +79,8 @@ class Detect(HipModule):
             feat = ops.new_act(b, self.no, h, w, self.cv2[i][0].out_dtype(xi), xi.device)
             pk01 = None if self.training else self._merged_first(i, xi, feat.dtype)
             if pk01 is not None:                              # both branches' first 3x3 conv read xi: one launch, cout = c2 + c3
-                t01 = ops.conv2d(xi, pk01, 1, ops.ACT_SILU)
+                xq = self.q8_site(('first01', i), xi) if feat.dtype == torch.bfloat16 else None
+                t01 = ops.conv2d(xi, pk01, 1, ops.ACT_SILU) if xq is None else ops.conv2d_fp8(xi, self._merged_first(i, xi, feat.dtype, xq), 1, ops.ACT_SILU)
                 c2 = self.cv2[i][0].conv.out_channels
                 tb, tc = self.cv2[i][1](t01[:, :c2]), self.cv3[i][1](t01[:, c2:])
             else:
@@ -114,7 +115,7 @@ class Detect(HipModule):
             a_off += f.shape[2] * f.shape[3]
         return y if self.export else (y, x)
 
-    def _merged_first(self, i, xi, dt):
+    def _merged_first(self, i, xi, dt, xq=None):
         """PackedConv of cat(cv2[i][0], cv3[i][0]) along cout (BN folded per branch), or None when the pair is not two plain
         3x3 Conv+BN+SiLU layers the MFMA kernel takes."""
         a, b = self.cv2[i][0], self.cv3[i][0]
@@ -125,9 +126,10 @@ class Detect(HipModule):
             return None
         tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
         cat = lambda f: torch.cat([f(a).detach().float(), f(b).detach().float()])
-        return self._cached(('first01', i, dt), tens, lambda: ops.PackedConv(
-            cat(lambda m: m.conv.weight), None,
-            (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps), 3, dt))
+        bn = lambda: (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        if xq is not None:      # the e4m3 panel of the same merged convolution (quantize_fp8)
+            return self._cached(('first01', i, 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), None, bn(), 3, xq))
+        return self._cached(('first01', i, dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), None, bn(), 3, dt))
 
     def backward(self, grads):
         """grads: list of d loss / d raw head maps (one per level, NHWC).  Returns the list of input gradients."""

@@ -223,6 +223,42 @@ class BaseModel(nn.Module):
         return self.set_compute_dtype(torch.float32)
 
     # -- MI355X-specific knobs (not in the reference) ------------------------------------------------------
+    def quantize_fp8(self, calib, headroom=2.0):
+        """fp8 inference (BASELINE configs[4]; the reference has no counterpart - trainer.py:223 is fp16 autocast only).  Every convolution
+        that runs on the implicit-GEMM kernel (`Conv.run` on the bf16 MFMA path) switches to e4m3 operands: weights with per-output-channel
+        scales (mgdt_conv_pack_fp8), activations with one power-of-two multiplier per convolution, chosen so that `headroom` x the largest
+        |input| seen on the calibration images `calib` (one batch or a list of batches) lands at the top of the e4m3 range (448).  Activations
+        stay bf16 in HBM; the block kernels (stem, CSP / MSPA blocks, ConvNeXt MLP, injection, detect tail) stay bf16.  Returns the
+        {module name: multiplier} table.  `dequantize_fp8()` restores the bf16 path."""
+        import math
+        self.set_compute_dtype(torch.bfloat16)
+        was_training = self.training
+        self.eval()
+        self.dequantize_fp8()
+        stats = {}
+        ops.Q8_CALIB = stats
+        try:
+            with torch.no_grad():
+                for xb in (calib if isinstance(calib, (list, tuple)) else [calib]):
+                    self._predict_once(xb)
+        finally:
+            ops.Q8_CALIB = None
+            self.train(was_training)
+        names = {m: n for n, m in self.named_modules()}
+        table = {}
+        for (m, key), amax in stats.items():
+            q = 1.0 if not (amax > 0.0 and math.isfinite(amax)) else 2.0 ** math.floor(math.log2(448.0 / (headroom * amax)))
+            m.__dict__.setdefault('_q8', {})[key] = q
+            table[names.get(m, '?') + ('' if key is None else ':' + '/'.join(str(k) for k in key))] = q
+        self.fp8_table = table
+        return table
+
+    def dequantize_fp8(self):
+        for m in self.modules():
+            m.__dict__.pop('_q8', None)
+        self.fp8_table = {}
+        return self
+
     def set_compute_dtype(self, dtype):
         """float32 (exact path, 1e-3 box parity) or bfloat16 (throughput path); parameters stay fp32 masters."""
         ops.dtype_code(dtype)

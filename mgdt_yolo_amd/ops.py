@@ -165,6 +165,49 @@ class PackedConv:
                 _register_pack(self, (weight, cb, g, b, mu, var, float(eps), cin_g, cout, k, code, 0))
 
 
+class PackedConvFp8:
+    """e4m3 panel of one convolution (BN folded, per-output-channel weight scales) for the activation multiplier `xq` - mgdt_conv_pack_fp8."""
+    __slots__ = ('w', 'bias', 'oscale', 'xq', 'k', 'cin', 'cout', 'dtype', 'direct', 'groups', '__weakref__')
+
+    def __init__(self, weight, conv_bias, bn, k, xq):
+        lib = L.lib()
+        weight = weight.detach().float().contiguous()
+        _need_gpu(weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        dev = weight.device
+        g, b, mu, var, eps = (None, None, None, None, 0.0) if bn is None else bn
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        g, b, mu, var, cb = f(g), f(b), f(mu), f(var), f(conv_bias)
+        self.k, self.cin, self.cout, self.dtype, self.direct, self.groups, self.xq = k, cin, cout, torch.bfloat16, False, 1, float(xq)
+        self.w = torch.empty(lib.mgdt_conv_packed_bytes_fp8(cin, cout, k), dtype=torch.uint8, device=dev)
+        cpad = (cout + 15) // 16 * 16
+        self.bias = torch.empty(cpad, dtype=torch.float32, device=dev)
+        self.oscale = torch.empty(cpad, dtype=torch.float32, device=dev)
+        _launch('conv_pack_fp8', 'mgdt_conv_pack_fp8', ptr(weight), ptr(cb), ptr(g), ptr(b), ptr(mu), ptr(var), eps, cin, cout, k, self.xq,
+                ptr(self.w), ptr(self.bias), ptr(self.oscale), stream())
+
+
+Q8_CALIB = None    # dict module -> running max|input| while BaseModel.quantize_fp8() runs its calibration batches
+
+
+def conv2d_fp8(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=None, in_shift=None):
+    """mgdt_conv2d_fp8_fwd: bf16 views, e4m3 operands on the MFMA, fp32 accumulation."""
+    _need_gpu(x)
+    b, _, h, w = x.shape
+    ho, wo = conv_out_hw(h, w, pk.k, stride)
+    if out is None:
+        out = new_act(b, pk.cout, ho, wo, torch.bfloat16, x.device)
+    _same(x, x2, r1, r2, out)
+    if x.dtype != torch.bfloat16:
+        raise RuntimeError(f'conv2d_fp8: activations are bf16 in HBM, the input is {x.dtype}')
+    if _PROF is not None:
+        _META['conv2d_fp8_fwd'] = dict(shape=(b, pk.cin, h, w, pk.cout, pk.k, stride), flops=2.0 * b * ho * wo * pk.cout * pk.cin * pk.k * pk.k,
+                                       bytes=float(b * h * w * pk.cin * 2 + b * ho * wo * pk.cout * 2 + pk.cout * pk.cin * pk.k * pk.k))
+    _launch('conv2d_fp8_fwd', 'mgdt_conv2d_fp8_fwd', vp(x), vp(x2), ptr(in_scale), ptr(in_shift), ptr(pk.w), ptr(pk.bias), ptr(pk.oscale), pk.xq,
+            pk.k, stride, act, vp(r1), vp(r2), vp(out), stream())
+    return out
+
+
 # ---- batched re-pack after an optimizer step -------------------------------------------------------------------------------------
 # Every packed panel built from live parameter storage registers (weakly) what it was built from.  `repack_all()` - called by the trainer
 # right after the HIP optimizer moved the weights - refreshes all panels that were valid for the step that just ran with
