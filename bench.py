@@ -298,7 +298,8 @@ def main():
                 pool = torch.cuda.graph_pool_handle()      # the R graphs replay one after the other: they share one activation pool
                 for r in range(R):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
+                    # several ranks: RCCL's watchdog thread may poll events while this thread captures - keep the capture's error mode thread-local
+                    with torch.cuda.graph(g, pool=pool, **({'capture_error_mode': 'thread_local'} if world > 1 else {})):
                         outs.append(step(xs[r]))
                     graphs.append(g)
                 out = outs[-1]

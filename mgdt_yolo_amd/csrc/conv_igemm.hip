@@ -346,7 +346,7 @@ template <typename T>
 static int dispatch_igemm(const ConvArgs& a, int NT, int MT, int gx, int gy, int threads, size_t lds, hipStream_t st) {
 #define CASE(nt, mt) \
   if (NT == nt && MT == mt) return launch_igemm<T, nt, mt, false>(a, gx, gy, threads, lds, st);
-  CASE(1, 2) CASE(1, 4) CASE(1, 8) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
+  CASE(1, 2) CASE(1, 4) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2) CASE(6, 2) CASE(8, 2)
 #undef CASE
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: no kernel for NT=%d MT=%d", NT, MT);
 }
@@ -453,7 +453,7 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   for (int c : {8, 6, 5, 4, 3, 2, 1})
     if (a.NTtot % c == 0 && (long)a.nchunks * c * WB <= LDS_PANEL_KIB * 1024L) { NT = c; break; }
   int MT = 2;   // MT=2 with depth-4 prefetch measured faster than MT=4 on every wide layer of the target nets
-  if (!q8 && NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e ? atoi(e) : 2; }
+  if (!q8 && NT == 1 && a.NTtot == 1) { const char* e = getenv("MGDT_CONV_MT1"); MT = e && atoi(e) == 4 ? 4 : 2; }   // (MT = 8 spilled registers: removed)
   int waves = 8;
   auto wgs = [&](int nt, int wv) { return (long)cdiv(M, 16 * wv * MT) * (a.NTtot / nt); };
   // (4-wave workgroups for small maps were tried: 8 waves measured faster on the whole net - fewer, fuller workgroups stage the weight panel less often)

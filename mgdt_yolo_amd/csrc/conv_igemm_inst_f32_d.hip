@@ -1,3 +1,2 @@
 #include "conv_igemm_kernel.h"
 template int launch_igemm<float, 1, 4>(const ConvArgs&, int, int, int, size_t, hipStream_t);
-template int launch_igemm<float, 1, 8>(const ConvArgs&, int, int, int, size_t, hipStream_t);
