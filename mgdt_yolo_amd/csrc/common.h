@@ -62,6 +62,30 @@ __device__ __forceinline__ float fast_sigmoid(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// fp8 (OCP e4m3fn on gfx950) operands: 8 values per lane in one 64-bit register, same (row, 8g..8g+7) K layout as the bf16 16x16x32 form,
+// same accumulator layout, the bf16 form's rate (MI355X_MICROARCH.md: non-scaled fp8 = bf16 cycles).
+__device__ __forceinline__ f32x4 mma_q8(long w, long p, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w, p, acc, 0, 0, 0);
+}
+// 8 bf16 activations -> 8 e4m3 bytes: x * xq, clamped to the finite e4m3 range (the conversion itself does not saturate), round-to-nearest-even
+__device__ __forceinline__ long quant8(bf16x8 v, float xq) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(2))) int i32x2;
+  const u32x4 d = __builtin_bit_cast(u32x4, v);
+  auto cv = [&](unsigned int w, float& lo, float& hi) __attribute__((always_inline)) {
+    lo = __builtin_amdgcn_fmed3f(__uint_as_float(w << 16) * xq, -448.f, 448.f);
+    hi = __builtin_amdgcn_fmed3f(__uint_as_float(w & 0xffff0000u) * xq, -448.f, 448.f);
+  };
+  float l0, h0, l1, h1, l2, h2, l3, h3;
+  cv(d[0], l0, h0); cv(d[1], l1, h1); cv(d[2], l2, h2); cv(d[3], l3, h3);
+  i32x2 o = {0, 0};
+  o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(l0, h0, o[0], false);
+  o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(l1, h1, o[0], true);
+  o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(l2, h2, o[1], false);
+  o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(l3, h3, o[1], true);
+  return __builtin_bit_cast(long, o);
+}
+
 // exact unsigned division by a runtime constant: q = mulhi(n, mul) >> sh  (n < 2^31), host-side magic numbers
 struct FastDiv { uint32_t mul, sh, d; };
 static inline FastDiv make_fastdiv(uint32_t d) {

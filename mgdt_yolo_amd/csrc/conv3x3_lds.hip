@@ -11,6 +11,7 @@
 //   * wave w owns tile rows 4w .. 4w+3 (MT = 4 pixel groups of 16) and all NBW cout blocks: NBW + 4 fragment reads feed 4*NBW MFMAs per K step; fragments are
 //     double-buffered in registers so the LDS reads of step k+1 are in flight under the MFMAs of step k;
 //   * the next tile's region is requested into registers before the current tile's MFMAs and written to LDS after them.
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -26,6 +27,7 @@ struct C3Args {
   const char* wpk; const float* bias;
   int N, H, W, Cin, Cout, CP, nchunks, NTtot, ncg, tiles_x, tiles_per_img, ntiles, XP, act;
   FastDiv fd_tpi, fd_tx, fd_cp;
+  const float* oscale; float xq; // Q8 kernels (fp8 inference): de-quantisation factor per output channel, activation multiplier (mgdt_conv_pack_fp8)
   unsigned long long* dbg;       // MGDT_C3_DBG: per workgroup {start, weights staged, sum(commit), sum(mfma), sum(epilogue), tiles} in 10 ns ticks
 };
 
@@ -39,13 +41,17 @@ template <int ACT> __device__ __forceinline__ float c3_act(float v) {
 // trip count it waited for every fragment right before its first use and the single wave per SIMD had nothing to hide that latency behind)
 // MT = pixel groups (tile rows) per wave: the tile is 4*MT rows x 16 columns (16x16 at MT = 4; 8x16 at MT = 2, for panels of 5 cout blocks x 80 input
 // channels that leave no room for the 18x18 region)
-template <int NBW, int ACT, int NCH, int MT>
+// Q8 (BASELINE configs[4]): e4m3 operands - the weight panel holds 512-byte blocks (mgdt_conv_pack_fp8), the region is converted to e4m3 when it is committed
+// to LDS (8 bytes per piece), fragments are ds_read_b64.  The bf16 MFMA phase is LDS-bandwidth bound (NBW + MT ds_read_b128 per NBW * MT MFMAs per wave = ~83 % of
+// 128 B/clk with 4 waves); e4m3 halves those bytes and the footprint, so two workgroups share a CU and one's staging / epilogue overlaps the other's MFMAs.
+template <int NBW, int ACT, int NCH, int MT, bool Q8 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   constexpr int TH = 4 * MT, RPX = (TH + 2) * C3_RW;            // tile rows, region pixels
+  constexpr int WB = Q8 ? 512 : 1024, PB = Q8 ? 8 : 16;         // bytes of a weight block / of an 8-channel piece in LDS
   extern __shared__ __attribute__((aligned(16))) char c3_lds[];
   int* tab = (int*)c3_lds;                                          // [nchunks * 4] byte offset of piece p inside the region, relative to the pixel's row
   char* wl = c3_lds + (((size_t)a.nchunks * 16 + 15) & ~(size_t)15);
-  char* xs = wl + (size_t)a.nchunks * NBW * 1024;
+  char* xs = wl + (size_t)a.nchunks * NBW * WB;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cg = blockIdx.x % a.ncg, w0 = blockIdx.x / a.ncg, wstep = gridDim.x / a.ncg;      // cout group, first tile, tile step of this workgroup
@@ -56,17 +62,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   // ---- once per workgroup: piece table and the weight panel of its cout blocks
   for (int p = tid; p < a.nchunks * 4; p += 256) {
     const int tap = (int)fdiv((uint32_t)p, a.fd_cp), cp = p - tap * a.CP;
-    tab[p] = tap < 9 ? ((tap / 3) * C3_RW + (tap % 3)) * a.XP + cp * 16 : 0;       // padding pieces carry zero weights: any in-range address
+    tab[p] = tap < 9 ? ((tap / 3) * C3_RW + (tap % 3)) * a.XP + cp * PB : 0;       // padding pieces carry zero weights: any in-range address
   }
-  for (int i = tid; i < a.nchunks * NBW * 64; i += 256) {
-    const int kc = i / (NBW * 64), rem = i - kc * NBW * 64, bw = rem >> 6, ln = rem & 63;
+  constexpr int WV = WB / 16;                                       // 16-byte vectors per weight block
+  for (int i = tid; i < a.nchunks * NBW * WV; i += 256) {
+    const int kc = i / (NBW * WV), rem = i - kc * NBW * WV, bw = rem / WV, ln = rem % WV;
     const bool ok = nb0 + bw < a.NTtot;
-    const uint4 v = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * 64 + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 v = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * WV + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
     *(uint4*)(wl + (size_t)i * 16) = v;
   }
-  f32x4 bias[NBW];
+  f32x4 bias[NBW], osc[Q8 ? NBW : 1];
 #pragma unroll
-  for (int bw = 0; bw < NBW; ++bw) bias[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nb0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int bw = 0; bw < NBW; ++bw) {
+    bias[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nb0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (Q8) {                                              // accumulators start from bias / oscale, the epilogue multiplies by oscale
+      osc[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.oscale + (nb0 + bw) * 16 + 4 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
+      bias[bw] = bias[bw] / osc[bw];
+    }
+  }
 
   // ---- staging of one tile's input region: item = (region pixel, 8-channel piece)
   const int nitems = RPX * a.CP;
@@ -91,12 +104,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
       const int it = tid + u * 256;
       if (it < nitems) {
         const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
-        *(uint4*)(xs + pix * a.XP + c8 * 16) = stage[u];
+        if constexpr (Q8) *(long*)(xs + pix * a.XP + c8 * 8) = quant8(__builtin_bit_cast(bf16x8, stage[u]), a.xq);
+        else *(uint4*)(xs + pix * a.XP + c8 * 16) = stage[u];
       }
     }
   };
 
-  const char* const wlane = wl + lane * 16;
+  const char* const wlane = wl + lane * PB;
   int bbase[MT];                                                     // region row address of this lane's pixel in the wave's pixel groups
 #pragma unroll
   for (int m = 0; m < MT; ++m) bbase[m] = ((wave * MT + m) * C3_RW + r) * a.XP;
@@ -121,13 +135,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
     for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[bw][m] = bias[bw];
-    bf16x8 A[2][NBW], B[2][MT];
+    typedef typename std::conditional<Q8, long, bf16x8>::type frag_t;
+    frag_t A[2][NBW], B[2][MT];
     auto load_frags = [&](int kc, int buf) {
       const int off = tab[kc * 4 + g];
 #pragma unroll
-      for (int bw = 0; bw < NBW; ++bw) A[buf][bw] = *(const bf16x8*)(wlane + (size_t)(kc * NBW + bw) * 1024);
+      for (int bw = 0; bw < NBW; ++bw) A[buf][bw] = *(const frag_t*)(wlane + (size_t)(kc * NBW + bw) * WB);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) B[buf][m] = *(const bf16x8*)(xs + bbase[m] + off);
+      for (int m = 0; m < MT; ++m) B[buf][m] = *(const frag_t*)(xs + bbase[m] + off);
+    };
+    auto mm = [&](frag_t w, frag_t p, f32x4 c) __attribute__((always_inline)) {
+      if constexpr (Q8) return mma_q8(w, p, c);
+      else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, p, c, 0, 0, 0);
     };
     load_frags(0, 0);
     if (NCH > 0) {
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 #pragma unroll
         for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc & 1][bw], B[kc & 1][m], acc[bw][m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[kc & 1][bw], B[kc & 1][m], acc[bw][m]);
       }
     } else {
       for (int kc = 0; kc < a.nchunks; kc += 2) {
@@ -145,13 +164,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 #pragma unroll
         for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][bw], B[0][m], acc[bw][m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[0][bw], B[0][m], acc[bw][m]);
         if (kc + 1 < a.nchunks) {
           if (kc + 2 < a.nchunks) load_frags(kc + 2, 0);
 #pragma unroll
           for (int bw = 0; bw < NBW; ++bw)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[bw][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][bw], B[1][m], acc[bw][m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[1][bw], B[1][m], acc[bw][m]);
         }
       }
     }
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
           const int co = (nb0 + bw) * 16 + 4 * g;
           bf16x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)c3_act<ACT>(acc[bw][m][j]);
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)c3_act<ACT>(Q8 ? acc[bw][m][j] * osc[Q8 ? bw : 0][j] : acc[bw][m][j]);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, o), yrs,
                                                 (pin && co < a.Cout) ? (uint32_t)(po + co * 2) : (uint32_t)C3_OOB, 0, 0);
         }
@@ -184,7 +203,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 }
 
 // true when the layer is launched here (the caller returns), false: conv_igemm takes it
-bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st) {
+bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st,
+                             const float* q8_oscale, float q8_xq) {
+  const bool q8 = q8_oscale != nullptr;                    // e4m3 panel from mgdt_conv_pack_fp8
   static const int mode = getenv("MGDT_CONV3_LDS") ? atoi(getenv("MGDT_CONV3_LDS")) : 1;      // experiment knob: 0 = never
   if (!mode) return false;
   const int Cin = x->c, Cout = y->c;
@@ -200,28 +221,46 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   a.y = (char*)y->p; a.ysn = (int)(y->sn * 2); a.ysh = (int)(y->sh * 2); a.ysw = (int)(y->sw * 2); a.y_bytes = (uint32_t)exty;
   a.wpk = (const char*)packed_w; a.bias = bias;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = Cin; a.Cout = Cout; a.CP = CP; a.nchunks = nchunks; a.NTtot = NTtot; a.act = act;
-  a.XP = Cin * 2 + 16;
+  a.XP = q8 ? Cin + 16 : Cin * 2 + 16;
+  a.oscale = q8_oscale; a.xq = q8_xq;
   // every cout block in ONE workgroup (the input region is then staged once per tile); layers whose whole weight panel does not fit next to the
   // region stay on the igemm kernel: splitting the couts over workgroups re-reads the input per group and measured no faster
   const int NBW = NTtot;
   if (NBW != 2 && NBW != 3 && NBW != 4 && NBW != 5 && NBW != 6) return false;
-  if (NBW == 5 && mode < 2) return false;                   // 80 couts: only the 8x16-tile form fits and it measured slower than the igemm kernel (66.9 vs 55 us at 80 -> 80, 80x80, B = 32); MGDT_CONV3_LDS=2 forces it
+  if (NBW == 5 && mode < 2 && !q8) return false;                   // 80 couts: only the 8x16-tile form fits and it measured slower than the igemm kernel (66.9 vs 55 us at 80 -> 80, 80x80, B = 32); MGDT_CONV3_LDS=2 forces it
   a.ncg = 1;
-  const size_t fixed = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * 1024;
+  const size_t fixed = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * (q8 ? 512 : 1024);
   int MT = 4;                                              // 16x16 tiles when the region fits next to the panel, else 8x16
   if (fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP > 160 * 1024) MT = 2;
   const size_t lds = fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP;
-  if (lds > 160 * 1024 || (NBW == 5 && MT != 2) || (NBW != 5 && MT != 4)) return false;      // instantiated: 5 blocks with 8x16 tiles, the others with 16x16
+  if (lds > 160 * 1024) return false;
+  if (q8 ? MT != 4 : ((NBW == 5 && MT != 2) || (NBW != 5 && MT != 4))) return false;         // instantiated: bf16 5 blocks with 8x16 tiles, everything else with 16x16
   const int TH = 4 * MT;
   a.tiles_x = cdiv(x->w, C3_TW);
   a.tiles_per_img = a.tiles_x * cdiv(x->h, TH);
   a.ntiles = x->n * a.tiles_per_img;
   if ((TH + 2) * C3_RW * CP > 256 * C3_MAXI) return false;
   a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
-  int nwg = 256 / a.ncg * a.ncg;                                                                // one workgroup per CU, a multiple of the cout groups
+  int nwg = (q8 && 2 * lds <= 160 * 1024 ? 512 : 256) / a.ncg * a.ncg;                          // one workgroup per CU (fp8: two when both fit in LDS), a multiple of the cout groups
   nwg = (int)std::min<long>(nwg, (long)a.ntiles * a.ncg);
   nwg = nwg / a.ncg * a.ncg;
   if (nwg < a.ncg) return false;
+ #define C3_LAUNCH_Q8(NB, ACTV)                                                                                      \
+  {                                                                                                                  \
+    static std::atomic<bool> qattr{false}, qattr18{false}, qattr23{false};                                            \
+    if (nchunks == 18) {                                                                                             \
+      if (!qattr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); qattr18 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 18, 4, true><<<nwg, 256, lds, st>>>(a);                                           \
+    } else if (nchunks == 23) {                                                                                      \
+      if (!qattr23) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 23, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); qattr23 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 23, 4, true><<<nwg, 256, lds, st>>>(a);                                           \
+    } else {                                                                                                         \
+      if (!qattr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); qattr = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 0, 4, true><<<nwg, 256, lds, st>>>(a);                                            \
+    }                                                                                                                \
+  }
+#define C3_ACT_Q8(NB) \
+  if (act == MGDT_ACT_SILU) C3_LAUNCH_Q8(NB, MGDT_ACT_SILU) else if (act == MGDT_ACT_RELU) C3_LAUNCH_Q8(NB, MGDT_ACT_RELU) else C3_LAUNCH_Q8(NB, MGDT_ACT_NONE)
 #define C3_LAUNCH(NB, ACTV, MTV)                                                                                          \
   {                                                                                                                  \
     static std::atomic<bool> attr{false}, attr18{false}, attr23{false};                                                                        \
@@ -241,8 +280,12 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   static unsigned long long* dbgbuf = nullptr;
   if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);
   a.dbg = dbgbuf;
-  if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
+  if (q8) {
+    if (NBW == 6) { C3_ACT_Q8(6) } else if (NBW == 5) { C3_ACT_Q8(5) } else if (NBW == 4) { C3_ACT_Q8(4) } else if (NBW == 3) { C3_ACT_Q8(3) } else { C3_ACT_Q8(2) }
+  } else if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
 #undef C3_ACT
+#undef C3_ACT_Q8
+#undef C3_LAUNCH_Q8
 #undef C3_LAUNCH
   if (dbgbuf) {
     std::vector<unsigned long long> h(256 * 6);

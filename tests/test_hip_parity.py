@@ -1560,6 +1560,8 @@ FP8_CONV_CASES = [  # (B, cin, h, w, cout, k, s, xq)
     (2, 32, 20, 24, 64, 3, 1, 16.0), (2, 64, 16, 16, 96, 3, 2, 32.0), (1, 128, 13, 17, 256, 1, 1, 8.0), (2, 256, 10, 10, 128, 1, 1, 64.0),
     (1, 40, 9, 9, 20, 3, 1, 16.0), (2, 512, 8, 8, 256, 1, 1, 16.0), (1, 16, 40, 40, 16, 3, 1, 1.0), (1, 192, 20, 20, 80, 3, 1, 16.0),
     (1, 2048, 6, 6, 32, 3, 1, 16.0),   # 576 K-chunks: the panel of one cout block does not fit in LDS (segmented staging)
+    # large maps, 32-80 input channels: the plain variant runs on the LDS-staged kernel's e4m3 form (conv3x3_lds_kernel<.., Q8>)
+    (1, 64, 128, 128, 96, 3, 1, 16.0), (1, 80, 128, 130, 80, 3, 1, 16.0), (2, 32, 96, 100, 48, 3, 1, 8.0), (1, 48, 130, 127, 32, 3, 1, 16.0),
 ]
 
 
