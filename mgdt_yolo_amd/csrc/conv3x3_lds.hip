@@ -42,8 +42,9 @@ template <int ACT> __device__ __forceinline__ float c3_act(float v) {
 // MT = pixel groups (tile rows) per wave: the tile is 4*MT rows x 16 columns (16x16 at MT = 4; 8x16 at MT = 2, for panels of 5 cout blocks x 80 input
 // channels that leave no room for the 18x18 region)
 // Q8 (BASELINE configs[4]): e4m3 operands - the weight panel holds 512-byte blocks (mgdt_conv_pack_fp8), the region is converted to e4m3 when it is committed
-// to LDS (8 bytes per piece), fragments are ds_read_b64.  The bf16 MFMA phase is LDS-bandwidth bound (NBW + MT ds_read_b128 per NBW * MT MFMAs per wave = ~83 % of
-// 128 B/clk with 4 waves); e4m3 halves those bytes and the footprint, so two workgroups share a CU and one's staging / epilogue overlaps the other's MFMAs.
+// to LDS (8 bytes per piece), fragments are ds_read_b64.  Half the LDS bytes and footprint: 80 -> 80 layers fit with 16x16 tiles (bf16: igemm kernel).  Measured
+// (B = 32, 80x80): 64 -> 96 48 us (bf16 form 48), 80 -> 80 44 us (bf16 igemm 49); MFMA phase 5.2 us per tile for 460 MFMAs per wave vs 5.5 us for 432 in bf16 - the
+// phase is not LDS-bandwidth bound, so halving the bytes buys little.
 template <int NBW, int ACT, int NCH, int MT, bool Q8 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   constexpr int TH = 4 * MT, RPX = (TH + 2) * C3_RW;            // tile rows, region pixels
@@ -241,7 +242,8 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   a.ntiles = x->n * a.tiles_per_img;
   if ((TH + 2) * C3_RW * CP > 256 * C3_MAXI) return false;
   a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
-  int nwg = (q8 && 2 * lds <= 160 * 1024 ? 512 : 256) / a.ncg * a.ncg;                          // one workgroup per CU (fp8: two when both fit in LDS), a multiple of the cout groups
+  int nwg = 256 / a.ncg * a.ncg;                                                                // one workgroup per CU, a multiple of the cout groups (the e4m3 form's LDS
+                                                                                                // footprint would let two share a CU at 64 -> 96, its ~370 registers do not)
   nwg = (int)std::min<long>(nwg, (long)a.ntiles * a.ncg);
   nwg = nwg / a.ncg * a.ncg;
   if (nwg < a.ncg) return false;
@@ -278,7 +280,7 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
 #define C3_ACT(NB, MTV) \
   if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU, MTV) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU, MTV) else C3_LAUNCH(NB, MGDT_ACT_NONE, MTV)
   static unsigned long long* dbgbuf = nullptr;
-  if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);
+  if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);   // nwg <= 256
   a.dbg = dbgbuf;
   if (q8) {
     if (NBW == 6) { C3_ACT_Q8(6) } else if (NBW == 5) { C3_ACT_Q8(5) } else if (NBW == 4) { C3_ACT_Q8(4) } else if (NBW == 3) { C3_ACT_Q8(3) } else { C3_ACT_Q8(2) }
