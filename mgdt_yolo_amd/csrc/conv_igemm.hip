@@ -448,7 +448,7 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
 
   // tile choice: NT = cout blocks per workgroup - as many as divide NTtot and keep the whole weight panel in LDS
   // (activations are then read NTtot/NT times; once when NT == NTtot), fewer when the grid would starve the 256 CUs
-  int LDS_PANEL_KIB = 128;
+  int LDS_PANEL_KIB = 144;   // measured (round 2, tools/knob_sweep.sh, B = 32 bf16): 96 -> 1.377, 128 -> 1.326, 144 / 150 -> 1.312 ms per step (NT 2 -> 4 on the 128 -> 256 stride-2 conv)
   { const char* e = getenv("MGDT_CONV_PANEL_KIB"); if (e) LDS_PANEL_KIB = atoi(e); }   // experiment knob (not part of the ABI)
   int NT = 1;
   for (int c : {8, 6, 5, 4, 3, 2, 1})
@@ -474,8 +474,9 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   if (panel <= (size_t)LDS_PANEL_KIB * 1024) { a.seg_chunks = a.nchunks; a.nseg = 1; }
   else { a.seg_chunks = 64; a.nseg = cdiv(a.nchunks, a.seg_chunks); }   // NT == 1 here: 64 KiB segments
   size_t lds = a.tab_bytes + (size_t)(q8 ? 2 : 1) * NT * 16 * sizeof(float) + (size_t)a.seg_chunks * NT * WB;
-  int gcap = waves == 8 ? 512 : 1024;
+  int gcap = waves == 8 ? 256 : 1024;   // measured with the 144 KiB panels: 256 -> 1.293, 384 -> 1.306, 512 -> 1.312 ms per step (one persistent workgroup per CU and cout group)
   { const char* e = getenv("MGDT_CONV_GCAP"); if (e) gcap = atoi(e); }
+  if (lds > 160 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "conv2d: %zu bytes of LDS for NT=%d, %d chunks", lds, NT, a.seg_chunks);   // cannot happen with panels <= 150 KiB (table <= 9.4 KiB)
   int gx = std::min(8 * a.T8, gcap), gy = a.NTtot / NT;   // persistent: ~2 (8-wave) / 4 (4-wave) workgroups per CU
   hipStream_t st = (hipStream_t)s;
   if (q8) return dispatch_igemm_q8(a, NT, gx, gy, waves * 64, lds, st);
