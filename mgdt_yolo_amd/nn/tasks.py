@@ -223,13 +223,14 @@ class BaseModel(nn.Module):
         return self.set_compute_dtype(torch.float32)
 
     # -- MI355X-specific knobs (not in the reference) ------------------------------------------------------
-    def quantize_fp8(self, calib, headroom=2.0):
+    def quantize_fp8(self, calib, headroom=2.0, exclude=()):
         """fp8 inference (BASELINE configs[4]; the reference has no counterpart - trainer.py:223 is fp16 autocast only).  Every convolution
         that runs on the implicit-GEMM kernel (`Conv.run` on the bf16 MFMA path) switches to e4m3 operands: weights with per-output-channel
         scales (mgdt_conv_pack_fp8), activations with one power-of-two multiplier per convolution, chosen so that `headroom` x the largest
         |input| seen on the calibration images `calib` (one batch or a list of batches) lands at the top of the e4m3 range (448).  Activations
-        stay bf16 in HBM; the block kernels (stem, CSP / MSPA blocks, ConvNeXt MLP, injection, detect tail) stay bf16.  Returns the
-        {module name: multiplier} table.  `dequantize_fp8()` restores the bf16 path."""
+        stay bf16 in HBM; the block kernels (stem, CSP / MSPA blocks, ConvNeXt MLP, injection, detect tail) stay bf16.  `exclude`: substrings of
+        module names (as in `named_modules()`, e.g. 'model.22.' = the Detect head) whose convolutions keep bf16 operands - the usual mixed-precision
+        policy when the last layers decide the score ranking.  Returns the {module name: multiplier} table.  `dequantize_fp8()` restores the bf16 path."""
         import math
         self.set_compute_dtype(torch.bfloat16)
         was_training = self.training
@@ -247,6 +248,8 @@ class BaseModel(nn.Module):
         names = {m: n for n, m in self.named_modules()}
         table = {}
         for (m, key), amax in stats.items():
+            if any(e in names.get(m, '?') + '.' for e in exclude):
+                continue
             q = 1.0 if not (amax > 0.0 and math.isfinite(amax)) else 2.0 ** math.floor(math.log2(448.0 / (headroom * amax)))
             m.__dict__.setdefault('_q8', {})[key] = q
             table[names.get(m, '?') + ('' if key is None else ':' + '/'.join(str(k) for k in key))] = q
