@@ -19,13 +19,13 @@
 #define C3_OOB ((int)0x80000000)
 #define C3_TW 16
 #define C3_RW 18
-#define C3_MAXI 14                     // 16-byte items a thread stages per tile: 324 * (Cin / 8) / 256, Cin <= 80 -> 12.7
+#define C3_MAXI 14                     // 16-byte items a thread stages per tile: 324 * (Cin / 8) / 256, Cin <= 80 -> 12.7  (stride 2: 18 = 561 * 8 / 256 for Cin = 64)
 
 struct C3Args {
   const char* x; int xsn, xsh, xsw; uint32_t x_bytes;
   char* y; int ysn, ysh, ysw; uint32_t y_bytes;
   const char* wpk; const float* bias;
-  int N, H, W, Cin, Cout, CP, nchunks, NTtot, ncg, tiles_x, tiles_per_img, ntiles, XP, act;
+  int N, H, W, Ho, Wo, Cin, Cout, CP, nchunks, NTtot, ncg, tiles_x, tiles_per_img, ntiles, XP, act;
   FastDiv fd_tpi, fd_tx, fd_cp;
   const float* oscale; float xq; // Q8 kernels (fp8 inference): de-quantisation factor per output channel, activation multiplier (mgdt_conv_pack_fp8)
   unsigned long long* dbg;       // MGDT_C3_DBG: per workgroup {start, weights staged, sum(commit), sum(mfma), sum(epilogue), tiles} in 10 ns ticks
@@ -45,9 +45,13 @@ template <int ACT> __device__ __forceinline__ float c3_act(float v) {
 // to LDS (8 bytes per piece), fragments are ds_read_b64.  Half the LDS bytes and footprint: 80 -> 80 layers fit with 16x16 tiles (bf16: igemm kernel).  Measured
 // (B = 32, 80x80): 64 -> 96 48 us (bf16 form 48), 80 -> 80 44 us (bf16 igemm 49); MFMA phase 5.2 us per tile for 460 MFMAs per wave vs 5.5 us for 432 in bf16 - the
 // phase is not LDS-bandwidth bound, so halving the bytes buys little.
-template <int NBW, int ACT, int NCH, int MT, bool Q8 = false>
+// S = 2 (round 2): the stride-2 down-sampling convolutions (32 -> 64 at 320 -> 160 .. 64 -> 128 at 80 -> 40).  Same structure; the region of a TH x 16 output
+// tile is (2 TH + 1) x 33 input pixels, lane r's pixel sits 2 r columns into its region row, and the cout blocks may be split over `ncg` workgroup groups
+// (each stages the region itself: 2 re-reads instead of the igemm kernel's 9 taps x cout groups through the texture path).
+template <int NBW, int ACT, int NCH, int MT, bool Q8 = false, int S = 1>
 __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
-  constexpr int TH = 4 * MT, RPX = (TH + 2) * C3_RW;            // tile rows, region pixels
+  constexpr int RW = 15 * S + 3, TH = 4 * MT, RH = (TH - 1) * S + 3, RPX = RH * RW;     // region width, tile rows, region rows, region pixels
+  constexpr int MAXI = S == 1 ? C3_MAXI : 18;
   constexpr int WB = Q8 ? 512 : 1024, PB = Q8 ? 8 : 16;         // bytes of a weight block / of an 8-channel piece in LDS
   extern __shared__ __attribute__((aligned(16))) char c3_lds[];
   int* tab = (int*)c3_lds;                                          // [nchunks * 4] byte offset of piece p inside the region, relative to the pixel's row
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   // ---- once per workgroup: piece table and the weight panel of its cout blocks
   for (int p = tid; p < a.nchunks * 4; p += 256) {
     const int tap = (int)fdiv((uint32_t)p, a.fd_cp), cp = p - tap * a.CP;
-    tab[p] = tap < 9 ? ((tap / 3) * C3_RW + (tap % 3)) * a.XP + cp * PB : 0;       // padding pieces carry zero weights: any in-range address
+    tab[p] = tap < 9 ? ((tap / 3) * RW + (tap % 3)) * a.XP + cp * PB : 0;       // padding pieces carry zero weights: any in-range address
   }
   constexpr int WV = WB / 16;                                       // 16-byte vectors per weight block
   for (int i = tid; i < a.nchunks * NBW * WV; i += 256) {
@@ -84,16 +88,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 
   // ---- staging of one tile's input region: item = (region pixel, 8-channel piece)
   const int nitems = RPX * a.CP;
-  uint4 stage[C3_MAXI];
+  uint4 stage[MAXI];
   auto issue = [&](int t) {
     const int n = (int)fdiv((uint32_t)t, a.fd_tpi), rt = t - n * a.tiles_per_img;
     const int tyi = (int)fdiv((uint32_t)rt, a.fd_tx), txi = rt - tyi * a.tiles_x;
-    const int iy0 = tyi * TH - 1, ix0 = txi * C3_TW - 1;
+    const int iy0 = tyi * TH * S - 1, ix0 = txi * C3_TW * S - 1;
 #pragma unroll
-    for (int u = 0; u < C3_MAXI; ++u) {
+    for (int u = 0; u < MAXI; ++u) {
       const int it = tid + u * 256;
       const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
-      const int py = pix / C3_RW, px = pix - py * C3_RW;
+      const int py = pix / RW, px = pix - py * RW;
       const int iy = iy0 + py, ix = ix0 + px;
       const bool ok = it < nitems && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       stage[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (uint32_t)(n * a.xsn + iy * a.xsh + ix * a.xsw + c8 * 16) : (uint32_t)C3_OOB, 0, 0));
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < C3_MAXI; ++u) {
+    for (int u = 0; u < MAXI; ++u) {
       const int it = tid + u * 256;
       if (it < nitems) {
         const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   const char* const wlane = wl + lane * PB;
   int bbase[MT];                                                     // region row address of this lane's pixel in the wave's pixel groups
 #pragma unroll
-  for (int m = 0; m < MT; ++m) bbase[m] = ((wave * MT + m) * C3_RW + r) * a.XP;
+  for (int m = 0; m < MT; ++m) bbase[m] = ((wave * MT + m) * S * RW + r * S) * a.XP;
 
   // every global load issued so far (bias, weights) is retired HERE: otherwise the compiler, unable to order them against the prefetches that are
   // pending at the loop's back edge, waits for vmcnt(0) - i.e. for the NEXT tile's prefetch - in front of the first MFMA of every tile
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int oy = tyi * TH + wave * MT + m, ox = txi * C3_TW + r;
-        const bool pin = oy < a.H && ox < a.W;
+        const bool pin = oy < a.Ho && ox < a.Wo;
         const int po = n * a.ysn + oy * a.ysh + ox * a.ysw;
 #pragma unroll
         for (int bw = 0; bw < NBW; ++bw) {
@@ -205,11 +209,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
 
 // true when the layer is launched here (the caller returns), false: conv_igemm takes it
 bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st,
-                             const float* q8_oscale, float q8_xq) {
+                             const float* q8_oscale, float q8_xq, int stride) {
   const bool q8 = q8_oscale != nullptr;                    // e4m3 panel from mgdt_conv_pack_fp8
   static const int mode = getenv("MGDT_CONV3_LDS") ? atoi(getenv("MGDT_CONV3_LDS")) : 1;      // experiment knob: 0 = never
   if (!mode) return false;
   const int Cin = x->c, Cout = y->c;
+  // stride 2 - instantiated: bf16, 4 cout blocks per workgroup, Cin = 32 / 64.  Measured (B = 32, bench step): 32 -> 64 at 160 -> 80 35.9 us (igemm 38-40): default;
+  // 64 -> 128 at 80 -> 40 35.4 us (igemm 34.9): only with MGDT_CONV3_LDS=3.  The 8x16-output tiles carry 72 / 144 MFMAs per wave, so a tile costs mostly its
+  // staging latency and two barriers with one workgroup per CU - the LDS route wins much less here than the byte counts suggest.
+  if (stride == 2 && (q8_oscale || Cin > 64 || NTtot % 4 || (nchunks != 9 && !(nchunks == 18 && mode >= 3)))) return false;
   if (Cin % 8 || Cin < 32 || Cin > 80 || Cout % 4 || Cout < 32 || (act != MGDT_ACT_SILU && act != MGDT_ACT_NONE && act != MGDT_ACT_RELU)) return false;
   const long M = (long)x->n * x->h * x->w;
   if (M < 16 * 1024 || x->h < 16 || x->w < 16) return false;                                    // small maps: the igemm kernel's finer tiles fill the chip better
@@ -221,26 +229,28 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   a.x = (const char*)x->p; a.xsn = (int)(x->sn * 2); a.xsh = (int)(x->sh * 2); a.xsw = (int)(x->sw * 2); a.x_bytes = (uint32_t)extx;
   a.y = (char*)y->p; a.ysn = (int)(y->sn * 2); a.ysh = (int)(y->sh * 2); a.ysw = (int)(y->sw * 2); a.y_bytes = (uint32_t)exty;
   a.wpk = (const char*)packed_w; a.bias = bias;
-  a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = Cin; a.Cout = Cout; a.CP = CP; a.nchunks = nchunks; a.NTtot = NTtot; a.act = act;
+  a.N = x->n; a.H = x->h; a.W = x->w; a.Ho = y->h; a.Wo = y->w; a.Cin = Cin; a.Cout = Cout; a.CP = CP; a.nchunks = nchunks; a.NTtot = NTtot; a.act = act;
   a.XP = q8 ? Cin + 16 : Cin * 2 + 16;
   a.oscale = q8_oscale; a.xq = q8_xq;
   // every cout block in ONE workgroup (the input region is then staged once per tile); layers whose whole weight panel does not fit next to the
   // region stay on the igemm kernel: splitting the couts over workgroups re-reads the input per group and measured no faster
-  const int NBW = NTtot;
+  const int NBW = stride == 2 ? 4 : NTtot;
   if (NBW != 2 && NBW != 3 && NBW != 4 && NBW != 5 && NBW != 6) return false;
-  if (NBW == 5 && mode < 2 && !q8) return false;                   // 80 couts: only the 8x16-tile form fits and it measured slower than the igemm kernel (66.9 vs 55 us at 80 -> 80, 80x80, B = 32); MGDT_CONV3_LDS=2 forces it
-  a.ncg = 1;
+  // (80 couts in bf16: the 8x16-tile form measured slower than the igemm kernel - 66.9 vs 55 us at 80 -> 80, 80x80, B = 32; the 12x16 form (MGDT_CONV3_LDS=3) 58.9 us; MGDT_CONV3_LDS=2 forces 8x16)
+  a.ncg = NTtot / NBW;
   const size_t fixed = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * (q8 ? 512 : 1024);
-  int MT = 4;                                              // 16x16 tiles when the region fits next to the panel, else 8x16
-  if (fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP > 160 * 1024) MT = 2;
-  const size_t lds = fixed + (size_t)(4 * MT + 2) * C3_RW * a.XP;
+  auto region = [&](int mt) { return stride == 2 ? (size_t)(8 * mt + 1) * 33 * a.XP : (size_t)(4 * mt + 2) * C3_RW * a.XP; };
+  int MT = stride == 2 ? 2 : 4;                            // stride 1: 16x16 tiles when the region fits next to the panel, else 12x16 (5 cout blocks), else 8x16; stride 2: 8x16
+  if (stride == 1 && fixed + region(MT) > 160 * 1024) MT = NBW == 5 && !q8 && mode >= 3 && fixed + region(3) <= 160 * 1024 ? 3 : 2;   // 12x16 tiles at 80 -> 80: 58.9 us vs 55 us igemm
+  const size_t lds = fixed + region(MT);
   if (lds > 160 * 1024) return false;
-  if (q8 ? MT != 4 : ((NBW == 5 && MT != 2) || (NBW != 5 && MT != 4))) return false;         // instantiated: bf16 5 blocks with 8x16 tiles, everything else with 16x16
+  if (NBW == 5 && !q8 && MT == 2 && mode < 2) return false;
+  if (stride == 1 && (q8 ? MT != 4 : ((NBW == 5 && MT == 4) || (NBW != 5 && MT != 4)))) return false;   // instantiated: bf16 5 blocks with 12x16 / 8x16 tiles, everything else 16x16
   const int TH = 4 * MT;
-  a.tiles_x = cdiv(x->w, C3_TW);
-  a.tiles_per_img = a.tiles_x * cdiv(x->h, TH);
+  a.tiles_x = cdiv(y->w, C3_TW);
+  a.tiles_per_img = a.tiles_x * cdiv(y->h, TH);
   a.ntiles = x->n * a.tiles_per_img;
-  if ((TH + 2) * C3_RW * CP > 256 * C3_MAXI) return false;
+  if ((stride == 2 ? (2 * TH + 1) * 33 * CP > 256 * 18 : (TH + 2) * C3_RW * CP > 256 * C3_MAXI)) return false;
   a.fd_tpi = make_fastdiv((uint32_t)a.tiles_per_img); a.fd_tx = make_fastdiv((uint32_t)a.tiles_x); a.fd_cp = make_fastdiv((uint32_t)CP);
   int nwg = 256 / a.ncg * a.ncg;                                                                // one workgroup per CU, a multiple of the cout groups (the e4m3 form's LDS
                                                                                                 // footprint would let two share a CU at 64 -> 96, its ~370 registers do not)
@@ -282,11 +292,23 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   static unsigned long long* dbgbuf = nullptr;
   if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);   // nwg <= 256
   a.dbg = dbgbuf;
-  if (q8) {
+#define C3_LAUNCH_S2(ACTV, NCHV)                                                                                      \
+  {                                                                                                                  \
+    static std::atomic<bool> sattr{false};                                                                           \
+    if (!sattr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); sattr = true; } \
+    conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2><<<nwg, 256, lds, st>>>(a);                                          \
+  }
+#define C3_ACT_S2(NCHV) \
+  if (act == MGDT_ACT_SILU) C3_LAUNCH_S2(MGDT_ACT_SILU, NCHV) else if (act == MGDT_ACT_RELU) C3_LAUNCH_S2(MGDT_ACT_RELU, NCHV) else C3_LAUNCH_S2(MGDT_ACT_NONE, NCHV)
+  if (stride == 2) {
+    if (nchunks == 9) { C3_ACT_S2(9) } else { C3_ACT_S2(18) }
+  } else if (q8) {
     if (NBW == 6) { C3_ACT_Q8(6) } else if (NBW == 5) { C3_ACT_Q8(5) } else if (NBW == 4) { C3_ACT_Q8(4) } else if (NBW == 3) { C3_ACT_Q8(3) } else { C3_ACT_Q8(2) }
-  } else if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
+  } else if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5 && MT == 3) { C3_ACT(5, 3) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
 #undef C3_ACT
 #undef C3_ACT_Q8
+#undef C3_ACT_S2
+#undef C3_LAUNCH_S2
 #undef C3_LAUNCH_Q8
 #undef C3_LAUNCH
   if (dbgbuf) {

@@ -338,7 +338,7 @@ extern "C" int mgdt_conv_pack_batch(const mgdt_pack_desc* d, int n, mgdt_stream 
 }
 
 bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void* packed_w, const float* bias, int act, int CP, int nchunks, int NTtot, hipStream_t st,
-                             const float* q8_oscale, float q8_xq);
+                             const float* q8_oscale, float q8_xq, int stride);
 
 template <typename T, int NT, int MT, bool Q8>
 int launch_igemm(const ConvArgs& a, int gx, int gy, int threads, size_t lds, hipStream_t st);   // defined in conv_igemm_inst_*.hip
@@ -440,8 +440,8 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   a.M = (int)M; a.HoWo = Ho * Wo;
   a.fd_howo = make_fastdiv((uint32_t)a.HoWo); a.fd_wo = make_fastdiv((uint32_t)Wo);
   // plain 3x3 stride-1 bf16 layers with 32-80 input channels on large maps: the LDS-staged kernel (conv3x3_lds.hip)
-  if (tapmode == 0 && dtype == MGDT_BF16 && k == 3 && stride == 1 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
-      mgdt_conv3x3_lds_launch(x, y, packed_w, bias, act, a.CP, a.nchunks, a.NTtot, (hipStream_t)s, q8_oscale, q8_xq)) {
+  if (tapmode == 0 && dtype == MGDT_BF16 && k == 3 && !(x2 && x2->p) && !in_scale && !in_shift && !(r1 && r1->p) && !(r2 && r2->p) &&
+      mgdt_conv3x3_lds_launch(x, y, packed_w, bias, act, a.CP, a.nchunks, a.NTtot, (hipStream_t)s, q8_oscale, q8_xq, stride)) {
     MGDT_CHECK_LAUNCH("conv2d(3x3 lds)");
     return MGDT_OK;
   }

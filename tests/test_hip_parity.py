@@ -1410,18 +1410,23 @@ def test_tood_model_trains_in_bf16_and_as_a_captured_step():
 C3_LDS_CASES = [  # (B, cin, cout, H, W, act, sliced views)
     (4, 64, 96, 80, 80, 'silu', False), (4, 80, 80, 80, 80, 'silu', False), (3, 32, 64, 72, 88, 'none', False), (2, 48, 48, 96, 100, 'relu', True),
     (5, 64, 32, 64, 64, 'silu', True), (2, 72, 80, 120, 90, 'none', False), (3, 80, 80, 76, 84, 'relu', True),
+    # stride 2 (8th field): the down-sampling convolutions 32 -> 64 / 64 -> 128 (one / two cout groups of 4 blocks), even, odd and ragged maps, sliced views
+    (4, 32, 64, 160, 160, 'silu', False, 2), (3, 64, 128, 80, 80, 'silu', False, 2), (3, 32, 64, 75, 91, 'none', True, 2), (2, 64, 64, 96, 100, 'relu', True, 2),
+    (2, 64, 192, 97, 90, 'silu', False, 2),
 ]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', C3_LDS_CASES, ids=[f'{c[1]}to{c[2]}_{c[3]}x{c[4]}_{c[5]}{"_view" if c[6] else ""}' for c in C3_LDS_CASES])
+@pytest.mark.parametrize('case', C3_LDS_CASES, ids=[f'{c[1]}to{c[2]}_{c[3]}x{c[4]}_{c[5]}{"_view" if c[6] else ""}{"_s2" if len(c) > 7 else ""}' for c in C3_LDS_CASES])
 def test_conv3x3_lds_staged_kernel(case):
     """3x3 stride-1 bf16 convolutions with 32-80 input channels on large maps go through conv3x3_lds.hip (activations staged in LDS, persistent
     workgroups holding the weight panel).  Against torch's fp32 conv2d of the same bf16-rounded tensors + folded BN + activation: the only
     differences are fp32 summation order and the final bf16 rounding (2^-8 relative) - asserted at 1.5 * 2^-8 of the largest output.  Ragged maps
     (not multiples of the 16x16 tile), cout groups that do not fill the last workgroup and channel-slice views included."""
     from mgdt_yolo_amd import ops
-    B, ci, co, H, W, act, view = case
+    B, ci, co, H, W, act, view = case[:7]
+    st = case[7] if len(case) > 7 else 1
+    Ho, Wo = ops.conv_out_hw(H, W, 3, st)
     gen = torch.Generator().manual_seed(ci + co + H)
     w = torch.randn(co, ci, 3, 3, generator=gen) / (3 * ci ** 0.5)
     bias = torch.randn(co, generator=gen) * 0.1
@@ -1430,16 +1435,17 @@ def test_conv3x3_lds_staged_kernel(case):
         t = fill.to(DEV).to(torch.bfloat16)
         if not view:
             return t.contiguous(memory_format=torch.channels_last)
-        big = torch.zeros(B, c + 24, H, W, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        big = torch.zeros(B, c + 24, *fill.shape[2:], device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
         big[:, 8:8 + c] = t
         return big[:, 8:8 + c]
     x = mk(ci, torch.randn(B, ci, H, W, generator=gen))
-    y = mk(co, torch.zeros(B, co, H, W))
+    y = mk(co, torch.zeros(B, co, Ho, Wo))
     pk = ops.PackedConv(w.to(DEV), bias.to(DEV), None, 3, torch.bfloat16)
     code = {'silu': ops.ACT_SILU, 'relu': ops.ACT_RELU, 'none': ops.ACT_NONE}[act]
-    ops.conv2d(x, pk, 1, code, out=y)
+    with ops.profile() as prof:
+        ops.conv2d(x, pk, st, code, out=y)
     wr = w.to(DEV).to(torch.bfloat16).float()
-    ref = torch.nn.functional.conv2d(x.float().contiguous(), wr, bias.to(DEV), 1, 1)
+    ref = torch.nn.functional.conv2d(x.float().contiguous(), wr, bias.to(DEV), st, 1)
     ref = {'silu': torch.nn.functional.silu, 'relu': torch.relu, 'none': lambda t: t}[act](ref)
     err = (y.float() - ref).abs().max().item()
     assert err < 1.5 * 2 ** -8 * ref.abs().max().item(), (err, ref.abs().max().item())
