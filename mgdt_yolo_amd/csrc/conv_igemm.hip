@@ -463,6 +463,12 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
     const int minwg = e ? atoi(e) : 128;               // measured: 64 -> 1.800, 128 -> 1.791, 256 -> 1.811, 512 -> 1.876 ms per step
     while (wgs(NT, waves) < minwg && NT > 1 && NT % 2 == 0) NT /= 2;    // ... and split the couts over workgroups
   }
+  {   // a grid a few workgroups larger than what is resident at once (~3 eight-wave workgroups per CU) runs a second, almost empty round at the first one's
+      // full cost: 32 -> 512 at 40x40 (B = 32) is 800 workgroups on 768 slots.  Halving NT gives twice as many half-size workgroups: two full rounds of half the work.
+    static const bool tail_split = !getenv("MGDT_CONV_NO_TAIL_SPLIT");     // experiment knob (not part of the ABI)
+    const long w0 = wgs(NT, waves);
+    if (tail_split && w0 > 768 && w0 <= 960 && NT % 2 == 0) NT /= 2;
+  }
   {   // experiment knob (not part of the ABI)
     const char* e;
     if ((e = getenv("MGDT_CONV_WAVES"))) waves = atoi(e);

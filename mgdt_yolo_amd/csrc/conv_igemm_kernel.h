@@ -269,11 +269,61 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
   // lane holds couts (nb0+nt)*16 + 4g .. +3 of pixel (mt, r); stores / residual loads go through bounds-checked descriptors, so
   // tail pixels and padded output channels need no branch.  The activation switch is hoisted out of the loops.
   const bool ragged = (nb0 + NT) * 16 > a.Cout;   // this workgroup's last cout block is partly padding
+  // bf16, NT >= 4: the four lanes (r, g = 0..3) of a pixel hold 4 couts (8 bytes) of each cout block; a 4x4 transpose over those lanes (two butterfly
+  // stages of ds_bpermute: partner g ^ 1, then g ^ 2) leaves lane g with all 16 couts of block 4q + g, so a pixel's 4 blocks leave as 128 contiguous bytes
+  // (two 16-byte stores per lane) instead of sixteen 8-byte pieces in four instructions - full-line writes for the output-heavy 1x1 convolutions.
+  constexpr bool WIDE = std::is_same<T, bf16>::value && NT >= 4;
+  constexpr int NTW = WIDE ? NT / 4 * 4 : 0;      // cout blocks stored through the transpose; the rest (NT = 5, 6) keep the 8-byte stores
   auto epilogue_act = [&](const TileState(&S)[MT], auto actf) __attribute__((always_inline)) {
+    if constexpr (WIDE) {
+      if (!ragged) {
+        const bool odd = (g & 1) != 0, hi = (g & 2) != 0;
+        const int pA = (lane ^ 16) << 2, pB = (lane ^ 32) << 2;
+        auto xch = [&](int addr, uint2 v) __attribute__((always_inline)) {
+          return make_uint2((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x), (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y));
+        };
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int q = 0; q < NTW / 4; ++q) {
+            uint2 a4[4], c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nt = 4 * q + j;
+              const int cob = ((nb0 + nt) * 16 + 4 * g) * SZ;
+              f32x4 v = acc[nt][mt];
+              if constexpr (Q8) v *= *(const f32x4*)(olds + nt * 16 + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+              if (a.r1) v += bload4<T>(r1rs, (uint32_t)S[mt].r1o + cob);
+              if (a.r2) v += bload4<T>(r2rs, (uint32_t)S[mt].r2o + cob);
+              bf16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+              a4[j] = __builtin_bit_cast(uint2, o);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {          // stage A, partner g ^ 1: c4[2h + (source & 1)] = block 2h + (g & 1) of the two lanes of my half
+              const uint2 x = xch(pA, odd ? a4[2 * h] : a4[2 * h + 1]);
+              c4[2 * h] = odd ? x : a4[2 * h];
+              c4[2 * h + 1] = odd ? a4[2 * h + 1] : x;
+            }
+            const uint2 x0 = xch(pB, hi ? c4[0] : c4[2]), x1 = xch(pB, hi ? c4[1] : c4[3]);    // stage B, partner g ^ 2
+            const uint2 b0 = hi ? x0 : c4[0], b1 = hi ? x1 : c4[1], b2 = hi ? c4[2] : x0, b3 = hi ? c4[3] : x1;   // b[source lane g'] = block 4q + g of source g'
+            const uint32_t off = (uint32_t)S[mt].yo + (uint32_t)(((nb0 + 4 * q + g) * 16) * SZ);
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4v;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4v{b0.x, b0.y, b1.x, b1.y}, yrs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4v{b2.x, b2.y, b3.x, b3.y}, yrs, off + 16u, 0, 0);
+          }
+        }
+      }
+    }
+    const int nt_first = (WIDE && !ragged) ? NTW : 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (nt < nt_first) continue;
         const int cob = ((nb0 + nt) * 16 + 4 * g) * SZ;
         const int dead = (ragged && cob >= a.Cout * SZ) ? MGDT_OOB : 0;
         f32x4 v = acc[nt][mt];
