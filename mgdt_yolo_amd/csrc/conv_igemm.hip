@@ -465,7 +465,8 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   }
   {   // a grid a few workgroups larger than what is resident at once (~3 eight-wave workgroups per CU) runs a second, almost empty round at the first one's
       // full cost: 32 -> 512 at 40x40 (B = 32) is 800 workgroups on 768 slots.  Halving NT gives twice as many half-size workgroups: two full rounds of half the work.
-    static const bool tail_split = !getenv("MGDT_CONV_NO_TAIL_SPLIT");     // experiment knob (not part of the ABI)
+    // Measured (r02f): that layer 30.6 -> 28.1 us, but the whole step 1.294 -> 1.322 ms (the next kernels start behind a longer tail of small workgroups): off by default.
+    static const bool tail_split = getenv("MGDT_CONV_TAIL_SPLIT") != nullptr;     // experiment knob (not part of the ABI)
     const long w0 = wgs(NT, waves);
     if (tail_split && w0 > 768 && w0 <= 960 && NT % 2 == 0) NT /= 2;
   }
