@@ -53,6 +53,20 @@ def _reconstructor(cls, base, state):            # copyreg._reconstructor(cls, o
     return cls() if isinstance(cls, type) else Stub()
 
 
+def _load_type(name):
+    """dill's spelling of a builtin type (`dill._dill._load_type('OrderedDict')`; the reference pickles with dill when it is importable,
+    trainer.py:424-428): the same allow-list as a GLOBAL opcode, anything else an inert stub class."""
+    if name == 'OrderedDict':
+        return OrderedDict
+    if name in _SAFE_BUILTINS:
+        return _SAFE_BUILTINS[name]
+    return type(str(name), (Stub,), {'__module__': 'stub:dill'})
+
+
+def _inert(*args, **kwargs):                     # dill._dill._create_function / _create_code / _create_cell ...: lambdas in the file become stubs
+    return Stub(*args)
+
+
 def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
     flat = storage                                 # 1-D tensor over the whole storage (see persistent_load)
     if len(size) == 0:
@@ -86,6 +100,9 @@ class _Reader(pickle.Unpickler):
             return getattr(torch, name)
         if module == 'copyreg' and name == '_reconstructor':
             return _reconstructor
+        if module in ('dill._dill', 'dill.dill'):
+            self.stubbed.add(f'{module}.{name}')
+            return _load_type if name == '_load_type' else _inert
         self.stubbed.add(f'{module}.{name}')
         return type(name, (Stub,), {'__module__': f'stub:{module}'})       # a fresh inert class; nothing is imported
 
@@ -95,7 +112,7 @@ class _Reader(pickle.Unpickler):
             raise pickle.UnpicklingError(f'unexpected persistent id {pid!r}')
         st, key, numel = pid[1], pid[2], pid[4]
         dtype = st.dtype if isinstance(st, _StorageType) else getattr(st, 'dtype', torch.uint8)
-        raw = self.zf.read(f'{self.prefix}/data/{key}')
+        raw = self.zf.read(f'{self.prefix}/data/{key}' if self.prefix else f'data/{key}')
         if numel == 0 or len(raw) == 0:
             return torch.zeros(0, dtype=dtype)
         return torch.frombuffer(bytearray(raw), dtype=dtype)

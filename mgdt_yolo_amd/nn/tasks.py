@@ -407,8 +407,16 @@ def torch_safe_load(weight):
                 raise RuntimeError(f'{weight}: the pickled {k} carries no model YAML dict')
             m = DetectionModel(deepcopy(cfg), ch=cfg.get('ch', 3), nc=cfg.get('nc'), verbose=False)
             sd = {kk: vv.float() for kk, vv in CK.module_state_dict(v).items()}
-            missing = [kk for kk in m.state_dict() if kk not in sd]
-            m.load_state_dict(intersect_dicts(sd, m.state_dict()), strict=False)
+            own = m.state_dict()
+            # the reference unpickles the module itself, so it can never load partially: a key of the rebuilt graph that the file lacks, or
+            # stores with another shape, is an error here too (derived buffers that every build recomputes are exempt)
+            exempt = lambda kk: kk.endswith(('num_batches_tracked', '.anchors', '.strides', 'dfl.conv.weight'))
+            missing = [kk for kk in own if kk not in sd and not exempt(kk)]
+            mismatched = [f'{kk}: file {tuple(sd[kk].shape)} vs graph {tuple(own[kk].shape)}' for kk in own if kk in sd and sd[kk].shape != own[kk].shape]
+            if missing or mismatched:
+                raise RuntimeError(f'{weight}: checkpoint does not match the graph its YAML builds - missing {missing[:8]}'
+                                   f'{" ..." if len(missing) > 8 else ""}; shape mismatches {mismatched[:8]}')
+            m.load_state_dict(intersect_dicts(sd, own), strict=False)
             names = st.get('names')
             if isinstance(names, dict):
                 m.names = dict(names)

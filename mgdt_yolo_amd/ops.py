@@ -231,12 +231,12 @@ def _register_pack(obj, src):
 
 
 def repack_all():
-    """Refresh every registered panel that was current before the last optimizer step (PARAM_EPOCH - 1)."""
+    """Refresh every registered panel that was current before the last optimizer step (PARAM_EPOCH - 1); returns them."""
     if not _PACK_REGISTRY:
-        return 0
+        return []
     live = [o for o in _PACK_REGISTRY if getattr(o, 'epoch', -2) == PARAM_EPOCH[0] - 1]
     if not live:
-        return 0
+        return []
     arr = (L.PackDesc * len(live))()
     for d, o in zip(arr, live):
         w, cb, g, b, mu, var, eps, cin, cout, k, code, mode = o.src
@@ -246,7 +246,7 @@ def repack_all():
     _launch('conv_pack_batch', 'mgdt_conv_pack_batch', arr, len(live), stream())
     for o in live:
         o.epoch = PARAM_EPOCH[0]
-    return len(live)
+    return live
 
 
 def pack_is_current(obj):

@@ -205,7 +205,7 @@ class DetectionTrainer:
                 return
         clip = ops.grad_clip_coef(st.grad, 10.0)
         ops.sgd_ema_step_dev(st.data[:st.n_param], st.grad, st.momentum_buf, st.wd, st.ema, st.data, S['hyper'], True, False, clip)
-        ops.repack_all()                            # next step's packed weights, all convolutions in a few launches
+        S['panels'] = ops.repack_all()              # next step's packed weights, all convolutions in a few launches
 
     def _graph_step(self, batch):
         st = self.state
@@ -217,7 +217,13 @@ class DetectionTrainer:
         if S is None or S['img'].shape != img.shape or S['img'].dtype != img.dtype:
             S = self._static = dict(img=torch.empty_like(img), hyper=torch.empty(4, dtype=torch.float32, device=img.device),
                                     calls=torch.zeros(1, dtype=torch.int32, device=img.device), gts={})
-            self._graphs = {}
+            self._graphs, self._pool = {}, None
+        # Every captured graph reads - and, in its trailing re-pack, rewrites - the packed weight panels that were current when it was
+        # captured.  They must stay the ONE live panel set: each graph holds strong references to them (the caches only hold the newest
+        # object), every replay stamps them with the new optimizer epoch (so the next capture / eager step reuses them instead of packing
+        # new ones and freeing these), and if anything else moved the weights without refreshing them the graphs are dropped.
+        if any(not ops.pack_is_current(o) for _, _, panels in self._graphs.values() for o in panels):
+            self._graphs, self._pool = {}, None
         if nmax not in S['gts']:
             S['gts'][nmax] = torch.zeros(b, nmax, 5, dtype=torch.float32, device=img.device)
         S['gt'] = S['gts'][nmax]
@@ -228,9 +234,11 @@ class DetectionTrainer:
         d = self.ema_decay * (1 - math.exp(-(st.steps + 1) / self.ema_tau))      # torch_utils.py:342 with updates = steps + 1
         S['hyper'].copy_(torch.tensor([self.lr, self.lr_bias, self.mom, d], dtype=torch.float32), non_blocking=True)
         S['calls'].fill_(int(self.crit.epoch))
-        if nmax not in self._graphs:
+        captured = nmax not in self._graphs
+        if captured:
             gs = []
             torch.cuda.synchronize()
+            epoch0 = ops.PARAM_EPOCH[0]
             for part in (('grad', 'update') if self.graph_split else (None,)):
                 g = torch.cuda.CUDAGraph()
                 # several ranks: the RCCL watchdog thread polls events while we capture, so only this thread's calls are checked
@@ -239,13 +247,20 @@ class DetectionTrainer:
                 if self._pool is None:
                     self._pool = g.pool()
                 gs.append(g)
-            self._graphs[nmax] = (gs, S['out5'])
-        gs, out5 = self._graphs[nmax]
+            assert ops.PARAM_EPOCH[0] == epoch0 + 1        # the capture walked through exactly one optimizer step on the host side
+            ops.PARAM_EPOCH[0] = epoch0                     # ... which has not run yet: the replay below is that step
+            for o in S['panels']:
+                o.epoch = epoch0
+            self._graphs[nmax] = (gs, S['out5'], list(S['panels']))
+        gs, out5, panels = self._graphs[nmax]
         gs[0].replay()
         if self.graph_split:
             parallel.all_reduce_mean_(st.grad)       # one flat message between the two replays (loss was scaled by world_size: trainer.py:337-338)
             gs[1].replay()
-        ops.PARAM_EPOCH[0] += 1                     # the replay moved the weights: packed-weight caches of any eager forward are stale
+        ops.PARAM_EPOCH[0] += 1                     # the replay moved the weights: packed-weight caches of any eager forward are stale ...
+        for _, _, ps in self._graphs.values():      # ... except the panels the replayed re-pack just refreshed in place
+            for o in ps:
+                o.epoch = ops.PARAM_EPOCH[0]
         st.steps += 1
         self.crit.epoch += 1
         self.last_opt_step = self.ni

@@ -11,6 +11,8 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3  # yolo/utils/torch_utils.py:254-256 (initialize_weights overrides BatchNorm2d.eps)
 BN_TRAIN = False  # tests flip this to restate Conv.forward in training mode (batch statistics, conv.py:36-38)
+BN_MOMENTUM = 0.03  # yolo/utils/torch_utils.py:254-256
+BN_RUNNING_OUT = None  # a dict here collects the running statistics a train-mode forward leaves behind (prefix -> (mean, var))
 
 
 # ----------------------------------------------------------------------------- a1: Conv
@@ -45,6 +47,13 @@ def conv(x, sd, p, s=1, act='silu', fused=False, g=1):
         return _act(F.conv2d(x, w2.to(x.dtype), b2.to(x.dtype), s, k // 2, 1, g), act)
     y = F.conv2d(x, w.to(x.dtype), None, s, k // 2, 1, g)
     if BN_TRAIN:
+        if BN_RUNNING_OUT is not None:
+            # nn.BatchNorm2d in training mode: running <- (1 - momentum) * running + momentum * batch, with the UNBIASED batch variance
+            with torch.no_grad():
+                n = y.numel() // y.shape[1]
+                mu, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=True) if n > 1 else y.var((0, 2, 3), unbiased=False)
+                BN_RUNNING_OUT[p + '.bn'] = ((1 - BN_MOMENTUM) * sd[p + '.bn.running_mean'].to(y.dtype) + BN_MOMENTUM * mu,
+                                             (1 - BN_MOMENTUM) * sd[p + '.bn.running_var'].to(y.dtype) + BN_MOMENTUM * var)
         y = F.batch_norm(y, None, None, sd[p + '.bn.weight'].to(x.dtype), sd[p + '.bn.bias'].to(x.dtype), True, 0.0, BN_EPS)
         return _act(y, act)
     y = F.batch_norm(y, sd[p + '.bn.running_mean'].to(x.dtype), sd[p + '.bn.running_var'].to(x.dtype),

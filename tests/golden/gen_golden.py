@@ -290,8 +290,73 @@ def letterbox_geom():
     save('letterbox', **arrs)
 
 
+# ------------------------------------------------------------------ one TRAINING step of the reference
+def train():
+    """The reference's own training call sequence on CPU (yolo/engine/trainer.py:334-343): `model.train()`; `loss, items = model(batch)`
+    (nn/tasks.py:33-46,204-216 -> v8DetectionLoss) ; `loss.backward()`.  Stored per model: the train-mode head maps (batch-statistics
+    BatchNorm, nn/modules/conv.py:36-38), loss and items, EVERY parameter gradient (whole when small, else a strided sample + l2 norm + sum)
+    and every BatchNorm running_mean / running_var / num_batches_tracked after the forward (momentum 0.03, unbiased variance:
+    yolo/utils/torch_utils.py:254-256)."""
+    from inputs import TRAIN_CASE, grad_sample, train_inputs
+    c = TRAIN_CASE
+    x, lab = train_inputs()
+    for tag, yname in E2E_MODELS.items():
+        m = build(yname + '.yaml', nc=c['nc'], seed=c['weight_seed']).train()
+        batch = dict(img=x.clone(), **{k: v.clone() for k, v in lab.items()})
+        feats = []
+        hk = m.model[-1].register_forward_hook(lambda mod, i, o: feats.extend(o))
+        loss, items = m(batch)
+        hk.remove()
+        loss.backward()
+        arrs = {'loss': loss.detach().numpy(), 'items': items.numpy(), 'stride': m.stride.numpy()}
+        for i, f in enumerate(feats):
+            arrs[f'feat{i}'] = f.detach().numpy()
+        names, nograd = [], []
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                nograd.append(k)
+                continue
+            names.append(k)
+            arrs['g/' + k], arrs['gst/' + k] = grad_sample(p.grad)
+        arrs['grad_names'] = '\n'.join(names)
+        arrs['nograd_names'] = '\n'.join(nograd)
+        for k, b in m.named_buffers():
+            if 'running_' in k or 'num_batches_tracked' in k:
+                arrs['bn/' + k] = b.detach().numpy()
+        print('train', tag, float(loss), items.tolist(), len(names), 'gradients;', 'no grad:', nograd)
+        save(f'train_{tag}', **arrs)
+
+
+# ------------------------------------------------------------------ a checkpoint written by the reference's classes (VERDICT r2 item 8f)
+def ref_ckpt():
+    """`torch.save` of the dict BaseTrainer.save_model builds (yolo/engine/trainer.py:411-436): 'model' is the pickled reference
+    DetectionModel in half precision (deepcopy(de_parallel(model)).half()), 'ema' likewise, plus epoch / best_fitness / updates /
+    train_args / date / version.  Globals inside the pickle are the REFERENCE's class paths (ultralytics.nn.tasks.DetectionModel,
+    ultralytics.nn.modules...), which is what nn/checkpoint.py must read without importing or executing anything.  The expected
+    weights are the seeded state_dict (name-keyed: mgdt_yolo_amd.seeding), rounded to fp16."""
+    from copy import deepcopy
+    from inputs import CKPT_CASE
+    try:                                     # trainer.py:424-428: dill if importable (it is, in this image), else pickle
+        import dill as pickle_module
+    except ImportError:
+        import pickle as pickle_module
+    m = build('mspa_c2f_gd_yolov8.yaml', nc=CKPT_CASE['nc'], seed=CKPT_CASE['weight_seed']).train()
+    targs = dict(box=7.5, cls=0.5, dfl=1.5, imgsz=640, model='mspa_c2f_gd_yolov8.yaml', task='detect')
+    m.args = targs                           # trainer.py:set_model_attributes attaches the hyper-parameters
+    m.names = {i: f'class{i}' for i in range(CKPT_CASE['nc'])}
+    half = deepcopy(m).half()
+    for p_ in half.parameters():             # torch_utils.py:401-402
+        p_.requires_grad = False
+    # save_model's keys (trainer.py:413-422) after strip_optimizer (torch_utils.py:395-403): model <- EMA copy in fp16, the rest None
+    ckpt = {'epoch': -1, 'best_fitness': None, 'model': half, 'ema': None, 'updates': None, 'optimizer': None, 'train_args': targs,
+            'date': '2026-01-01T00:00:00', 'version': '8.0.120'}
+    path = os.path.join(HERE, 'ref_last.pt')
+    torch.save(ckpt, path, pickle_module=pickle_module)
+    print(f'ref_last.pt: {os.path.getsize(path) / 1024:.1f} KiB, pickled with {pickle_module.__name__}')
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match', 'optim_groups', 'metrics_ap', 'boxes2', 'letterbox']
+    what = sys.argv[1:] or ['train', 'ref_ckpt', 'e2e', 'modules', 'boxes', 'assigner', 'loss', 'nms', 'val_match', 'optim_groups', 'metrics_ap', 'boxes2', 'letterbox']
     models = {}
     if 'e2e' in what or 'nms' in what:
         for tag, yname in E2E_MODELS.items():
@@ -316,3 +381,7 @@ if __name__ == '__main__':
         boxes2()
     if 'letterbox' in what:
         letterbox_geom()
+    if 'train' in what:
+        train()
+    if 'ref_ckpt' in what:
+        ref_ckpt()

@@ -142,3 +142,31 @@ def scale_box_inputs(k, n=64):
 
 LETTERBOX_CASES = [((480, 640), 640, False), ((1080, 1920), 640, True), ((333, 500), (384, 640), False), ((640, 640), 640, True), ((721, 1283), 640, True),
                    ((100, 60), 320, False)]     # (source (h, w), new_shape, auto)
+
+
+# ---------------------------------------------------------------- reference TRAINING step (train-mode forward, loss, backward, BN running stats)
+TRAIN_CASE = dict(B=4, hw=(96, 96), nc=4, img_seed=13, label_seed=9, max_boxes=6, min_boxes=2, weight_seed=0)
+TRAIN_FULL_NUMEL = 2048          # gradients up to this size are stored whole, larger ones as a strided sample + [l2 norm, sum]
+
+
+def train_inputs():
+    """(images fp32 in [0,1), label dict) of the training fixture; boxes sized so that every GT contains anchor centres at stride 8."""
+    from mgdt_yolo_amd.seeding import seeded_images
+    c = TRAIN_CASE
+    x = seeded_images(c['B'], *c['hw'], seed=c['img_seed'])
+    lab = seeded_labels(c['B'], c['nc'], seed=c['label_seed'], max_boxes=c['max_boxes'], min_boxes=c['min_boxes'])
+    lab['bboxes'][:, 2:] = lab['bboxes'][:, 2:] * 0.5 + 0.1
+    return x, lab
+
+
+def grad_sample(g):
+    """The stored form of one gradient tensor: (values, [l2 norm, sum]) - whole if small, else TRAIN_FULL_NUMEL strided entries."""
+    f = g.detach().reshape(-1).double()
+    st = np.array([f.norm().item(), f.sum().item()], np.float64)
+    if f.numel() <= TRAIN_FULL_NUMEL:
+        return f.float().numpy(), st
+    step = f.numel() // TRAIN_FULL_NUMEL
+    return f[::step][:TRAIN_FULL_NUMEL].float().numpy(), st
+
+
+CKPT_CASE = dict(nc=2, weight_seed=5, epoch=7)       # the reference-class checkpoint tests/golden/ref_last.pt (trainer.py:413-422 layout)

@@ -250,3 +250,114 @@ def test_letterbox_geometry_matches_reference(golden):
     im = r.integers(0, 256, (13, 17, 3), dtype=np.uint8)
     assert np.array_equal(OM.resize_linear_u8(im, 17, 13), im)
     assert (OM.resize_linear_u8(np.full((9, 11, 3), 77, np.uint8), 23, 31) == 77).all()
+
+
+def check_train_fixture(g, loss, items, feats, grads, running, tol):
+    """Shared by the CPU (oracle) and GPU (HIP) tests: one training step against tests/golden/train_<tag>.npz, i.e. against what the
+    REFERENCE's `model.train()(batch)` + `loss.backward()` produced on CPU (gen_golden.py:train).  `grads`: name -> tensor, `running`:
+    BN prefix -> (mean, var).  tol = dict(feat=, loss=, grad=, grad_abs=, run=): grad is the per-tensor error in units of that tensor's l2 norm
+    (measured on the stored sample), with tensors whose reference gradient is analytically ~0 held to grad_abs * the typical norm instead."""
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=tol['loss'])
+    np.testing.assert_allclose(np.asarray(items, np.float64), g['items'], rtol=tol['loss'])
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(np.asarray(f), g[f'feat{i}'], atol=tol['feat'], rtol=tol['feat'])
+    names = str(g['grad_names']).split('\n')
+    norms = np.array([g['gst/' + k][0] / np.sqrt(max(np.prod(np.shape(grads[k])), 1)) for k in names if k in grads])
+    typical = float(np.median(norms))
+    worst = (0.0, None)
+    for k in names:
+        assert k in grads and grads[k] is not None, f'no gradient for {k}'
+        got, st = GI.grad_sample(grads[k])
+        ref, rst = g['g/' + k], g['gst/' + k]
+        rms_ref = rst[0] / np.sqrt(max(np.prod(np.shape(grads[k])), 1))
+        denom = max(rms_ref, tol['grad_abs'] * typical)
+        err = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) / denom)
+        nerr = abs(st[0] - rst[0]) / (denom * np.sqrt(max(np.prod(np.shape(grads[k])), 1)))
+        err = max(err, nerr)
+        if err > worst[0]:
+            worst = (err, k)
+        assert err < tol['grad'], (k, err, rms_ref, typical)
+    n_run = 0
+    for key in g.files:
+        if key.startswith('bn/') and key.endswith('running_mean'):
+            pre = key[3:-len('.running_mean')]
+            mu, var = running[pre]
+            np.testing.assert_allclose(np.asarray(mu), g[key], atol=tol['run'], rtol=tol['run'], err_msg=pre)
+            np.testing.assert_allclose(np.asarray(var), g[f'bn/{pre}.running_var'], atol=tol['run'], rtol=tol['run'], err_msg=pre)
+            n_run += 1
+    assert n_run > 40
+    return worst
+
+
+@pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
+def test_training_step_matches_reference(golden, tag):
+    """The oracle's TRAIN-mode branch (batch-statistics BatchNorm, oracle/layers.py BN_TRAIN) + loss + torch autograd against the reference's
+    own CPU training step: head maps, loss, items, all ~200 parameter gradients and every BN running statistic.  This pins the branch every
+    HIP gradient / batch-stat test is compared with."""
+    g = golden('train_' + tag)
+    c = GI.TRAIN_CASE
+    name = GI.E2E_MODELS[tag]
+    shapes, strides = model_shapes(name, nc=c['nc'])
+    sd = oracle_state_dict(shapes, c['weight_seed'])
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k and 'dfl' not in k) for k, v in sd.items()}
+    x, lab = GI.train_inputs()
+    OL.BN_TRAIN, OL.BN_RUNNING_OUT = True, {}
+    try:
+        feats = OL.model_forward(get_config(name, 'n', c['nc']), sd, x, strides, decode=False)
+        total, items, _ = OLoss.detection_loss(feats, lab, strides, 4, c['nc'], call_count=0)
+        total.backward()
+        running = {k: (m.numpy(), v.numpy()) for k, (m, v) in OL.BN_RUNNING_OUT.items()}
+    finally:
+        OL.BN_TRAIN, OL.BN_RUNNING_OUT = False, None
+    grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
+    assert str(g['nograd_names']).split('\n') == [k for k in shapes if k.endswith('dfl.conv.weight')]
+    worst = check_train_fixture(g, total.detach(), items, [f.detach().numpy() for f in feats], grads, running,
+                                dict(feat=2e-4, loss=2e-5, grad=2e-3, grad_abs=1e-2, run=1e-5))
+    print('worst gradient error (in units of the tensor rms)', worst)
+
+
+def test_reference_class_checkpoint_is_read_without_unpickling_code():
+    """tests/golden/ref_last.pt was written by the REFERENCE's classes (gen_golden.py:ref_ckpt: save_model's dict, trainer.py:413-422, after
+    strip_optimizer, pickled with dill as the reference does when dill is importable): its globals are ultralytics.nn.tasks.DetectionModel,
+    ultralytics.nn.modules.block.MSPA_C2f, ... - none of which exists on this side.  nn/checkpoint.py must recover YAML, names, args and
+    every weight (fp16-rounded seeded values) without importing or running anything the file names."""
+    import os
+    from mgdt_yolo_amd.nn.tasks import attempt_load_one_weight
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_last.pt')
+    model, ckpt = attempt_load_one_weight(path)
+    c = GI.CKPT_CASE
+    assert ckpt['epoch'] == -1 and ckpt['ema'] is None and ckpt['optimizer'] is None and ckpt['version'] == '8.0.120'
+    assert ckpt['train_args']['model'] == 'mspa_c2f_gd_yolov8.yaml'
+    assert model.names == {i: f'class{i}' for i in range(c['nc'])} and model.args['box'] == 7.5 and model.yaml['nc'] == c['nc']
+    assert any(s.startswith('ultralytics.nn.') for s in model.ckpt_stubbed_globals) and 'dill._dill._load_type' in model.ckpt_stubbed_globals
+    assert not any(k.startswith('ultralytics') for k in __import__('sys').modules), 'reading the file must not import what it names'
+    n = 0
+    for k, v in model.state_dict().items():
+        e = seeded_tensor(k, v.shape, c['weight_seed'])
+        if e is not None:
+            assert torch.equal(v, e.half().float()), k
+            n += 1
+    assert n > 300 and not model.training
+
+
+def test_checkpoint_that_does_not_match_its_graph_is_refused(tmp_path):
+    """a state_dict key that is missing or has another shape must raise (the reference cannot load partially)."""
+    import os
+    import zipfile
+    from mgdt_yolo_amd.nn import checkpoint as CK
+    from mgdt_yolo_amd.nn import tasks as T
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_last.pt')
+    real = CK.module_state_dict
+
+    def drop_one(mod, prefix=''):
+        sd = real(mod, prefix)
+        if not prefix:
+            sd.pop('model.3.conv.weight')
+            sd['model.0.bn.weight'] = sd['model.0.bn.weight'][:8]
+        return sd
+    CK.module_state_dict = drop_one
+    try:
+        with pytest.raises(RuntimeError, match='model.3.conv.weight'):
+            T.torch_safe_load(path)
+    finally:
+        CK.module_state_dict = real
