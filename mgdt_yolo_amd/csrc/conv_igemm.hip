@@ -472,7 +472,7 @@ static int conv2d_fwd_impl(const mgdt_view* x, const mgdt_view* x2, const float*
   }
   {   // experiment knob (not part of the ABI)
     const char* e;
-    if ((e = getenv("MGDT_CONV_WAVES"))) waves = atoi(e);
+    if ((e = getenv("MGDT_CONV_WAVES"))) waves = std::min(8, std::max(1, atoi(e)));   // __launch_bounds__(512): at most 8 waves per workgroup
   }
   a.numTiles = cdiv(M, 16 * waves * MT);
   a.T8 = cdiv(a.numTiles, 8);

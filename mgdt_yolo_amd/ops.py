@@ -888,7 +888,7 @@ def gconv_wgrad(x, dy, k, stride, groups, dw, accumulate=False):
 
 def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
     lib = L.lib()
-    if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype in (torch.float32, torch.uint8) and x2 is None and not accumulate and x.shape[1] < 4:
+    if (not is_nhwc(x) or x.shape[1] % 4) and x.dtype in (torch.float32, torch.uint8, torch.bfloat16) and x2 is None and not accumulate and x.shape[1] < 4:
         # the 3-channel image (NCHW): one strided copy into a 4-channel NHWC buffer (4th channel zero) puts the stem on the tiled NHWC kernel;
         # the generic kernel would scan every pixel once per weight element
         b, c, h, w = x.shape
@@ -899,7 +899,11 @@ def conv_wgrad(x, dy, k, stride, dw, dbias=None, x2=None, accumulate=False):
         flush_wgrad()                                  # dw4 is read right below
         copy(dw4[:, :c], dw)
         return
-    _same(x, dy, x2)
+    if is_nhwc(x) and x.shape[1] % 4 == 0 and dy.shape[1] % 4 == 0:
+        _same(x, dy, x2)
+    elif x.dtype != torch.float32 or dy.dtype not in (torch.float32, torch.bfloat16):
+        # the generic kernel (any layout, any channel count) reads x as fp32 whatever dy is: any other dtype would be an out-of-range read
+        raise RuntimeError(f'conv_wgrad: the generic (non-NHWC / channels % 4 != 0) path takes an fp32 input, got {x.dtype} (dy {dy.dtype})')
     ws = torch.empty(lib.mgdt_conv_wgrad_workspace_bytes(x.shape[1], dy.shape[1], k), dtype=torch.uint8, device=x.device)
     if _PROF is not None:
         b, ci, h, w = x.shape

@@ -19,27 +19,28 @@ class LetterBox:
         self.stride = stride
 
     def geometry(self, shape):
-        """(h, w) of the source -> (out_h, out_w, new_unpad_h, new_unpad_w, top, left, ratio, (dw, dh)); augment.py:554-583."""
-        new_shape = self.new_shape
-        if isinstance(new_shape, int):
-            new_shape = (new_shape, new_shape)
-        r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+        """Source (h, w) -> (out_h, out_w, resized_h, resized_w, top, left, ratio, (pad_w / 2, pad_h / 2)).  The rule is the reference's
+        (augment.py:554-583) and its rounding is part of the contract (fixtures tests/golden/letterbox.npz): one scale for both axes unless
+        scaleFill, resized side = round(side * scale), the leftover split in halves with the odd pixel going to the bottom / right edge
+        (round(half - 0.1) before, round(half + 0.1) after)."""
+        src_h, src_w = shape[0], shape[1]
+        dst_h, dst_w = (self.new_shape, self.new_shape) if isinstance(self.new_shape, int) else self.new_shape[:2]
+        scale = min(dst_h / src_h, dst_w / src_w)
         if not self.scaleup:
-            r = min(r, 1.0)
-        ratio = r, r
-        new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
-        dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
-        if self.auto:
-            dw, dh = np.mod(dw, self.stride), np.mod(dh, self.stride)
-        elif self.scaleFill:
-            dw, dh = 0.0, 0.0
-            new_unpad = (new_shape[1], new_shape[0])
-            ratio = new_shape[1] / shape[1], new_shape[0] / shape[0]
-        dw /= 2
-        dh /= 2
-        top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
-        left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
-        return new_unpad[1] + top + bottom, new_unpad[0] + left + right, new_unpad[1], new_unpad[0], top, left, ratio, (dw, dh)
+            scale = min(scale, 1.0)
+        ratio = (scale, scale)
+        res_w, res_h = int(round(src_w * scale)), int(round(src_h * scale))
+        pad_w, pad_h = dst_w - res_w, dst_h - res_h
+        if self.auto:                                  # minimal rectangle: pad only up to the next multiple of the stride
+            pad_w, pad_h = np.mod(pad_w, self.stride), np.mod(pad_h, self.stride)
+        elif self.scaleFill:                           # stretch to the target, no border
+            pad_w, pad_h, res_w, res_h = 0.0, 0.0, dst_w, dst_h
+            ratio = (dst_w / src_w, dst_h / src_h)
+        half_w, half_h = pad_w / 2, pad_h / 2
+        before = lambda half: int(round(half - 0.1))
+        after = lambda half: int(round(half + 0.1))
+        top, left = before(half_h), before(half_w)
+        return res_h + top + after(half_h), res_w + left + after(half_w), res_h, res_w, top, left, ratio, (half_w, half_h)
 
     def __call__(self, labels=None, image=None, out=None):
         """image: uint8 (h, w, 3) BGR tensor on the device (or numpy array, copied once).  Returns the letter-boxed image as uint8 (3, H, W) RGB

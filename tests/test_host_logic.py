@@ -308,3 +308,14 @@ def test_bench_refuses_to_report_fewer_ranks_than_requested():
     r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and '"value"' not in r.stdout
     assert 'torch.distributed' in r.stderr or 'ChildFailedError' in r.stderr or 'Traceback' in r.stderr      # the child launcher really ran
+
+
+def test_make_anchors_equals_the_pinned_oracle():
+    """yolo/utils/tal.py:make_anchors (flat-index construction) == oracle.layers.make_anchors (pinned through the e2e fixtures), odd sizes."""
+    import torch
+    from mgdt_yolo_amd.yolo.utils.tal import make_anchors
+    from oracle.layers import make_anchors as oracle_anchors
+    shapes, strides = [(5, 7), (3, 4), (1, 1), (80, 80)], [8, 16, 32, 8]
+    a, s = make_anchors([torch.zeros(2, 4, h, w) for h, w in shapes], strides)
+    b, t = oracle_anchors(shapes, strides)
+    assert torch.equal(a, b) and torch.equal(s, t) and a.shape == (sum(h * w for h, w in shapes), 2)

@@ -19,6 +19,13 @@ def read(path, counter):
 
 f, w = read(sys.argv[1], 'FETCH_SIZE'), read(sys.argv[2], 'WRITE_SIZE')
 commit = sys.argv[3] if len(sys.argv) > 3 else None
+# sys.argv[4]: the bench line the FETCH pass printed (gpurun_out/<tag>_pmc_bench_FETCH_SIZE.json): its roofline.launch_signature is the
+# fingerprint of the launch set that was measured; bench.py reports the stored traffic only for that same set
+signature = None
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    for line in open(sys.argv[4]):
+        if line.startswith('{'):
+            signature = json.loads(line).get('roofline', {}).get('launch_signature')
 rows = []
 for k in f:
     n = f[k][1]
@@ -32,7 +39,7 @@ conv = [(n, r, wr) for k, n, r, wr in rows if 'conv_igemm_kernel' in k or 'conv3
 if conv:
     tot = sum(n for n, _, _ in conv)
     by = sum(n * (r + wr) for n, r, wr in conv) / tot
-    ent = {'hbm_bytes_per_launch': round(by), 'launches_averaged': tot, 'measured_at': commit,
+    ent = {'hbm_bytes_per_launch': round(by), 'launches_averaged': tot, 'measured_at': commit, 'launch_signature': signature,
            'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_pmc.sh, eager bench pass), averaged over the conv_igemm_kernel launches of a step; '
                      'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as read'}
     p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

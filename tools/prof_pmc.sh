@@ -4,6 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$1_$c
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$1_$c -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline $BENCH_ARGS > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$1_$c -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/$1_pmc_bench_$c.json 2> /dev/null
   python3 $R/tools/read_rocpd.py /tmp/pmc_$1_$c | grep "$c" > $R/gpurun_out/$1_pmc_$c.txt
 done
