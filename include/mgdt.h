@@ -118,10 +118,11 @@ int mgdt_stem2_fwd(const mgdt_view* x, int x_dtype, const void* packed0, const f
 /* ---- Detect head tail in one launch, bf16 (nn/modules/head.py:150-177): the two final 1x1 convs with bias (box c2 -> 16, cls c3 -> nc), the raw
  * (N, 16+nc, H, W) map and its decode (DFL expectation, dist2bbox, stride, sigmoid) into y[N][4+nc][a_total] at anchor offset a_off.
  * wb/bb, wc/bc: mgdt_conv_pack(c2, 16, 1, bf16) / mgdt_conv_pack(c3, nc, 1, bf16) with the conv biases.  reg_max must be 4 (this fork's
- * Detect); other heads keep mgdt_conv2d_fwd + mgdt_detect_decode_fwd. */
+ * Detect); other heads keep mgdt_conv2d_fwd + mgdt_detect_decode_fwd.  best_keys: NULL, or [N][a_total] - per anchor the NMS key of its
+ * best class (first maximal score, ops.py:225-226), see mgdt_nms_fwd. */
 int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, int dtype);
 int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
-                         float stride, int a_off, int a_total, const mgdt_view* feat, float* y, mgdt_stream s);
+                         float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys, mgdt_stream s);
 
 /* ---- a whole CSP block (MSPA_C2f / C2f) in one launch, bf16 inference (nn/modules/block.py:187-287, :514-526):
  *   mode 0 (MSPA_C2f): front = the three chained 1x1 convs of mgdt_pw_chain3_fwd (blob of mgdt_pw_chain_pack), bottleneck input
@@ -251,11 +252,13 @@ int mgdt_detect_decode_fwd(const mgdt_view* feat, int reg_max, int nc, float str
 /* ---- batched NMS (yolo/utils/ops.py:136-266 incl. the torchvision.ops.nms call at :249) -----------------
  * pred fp32 [n][4+nc][a].  Outputs per image: out[n][max_det][6] fp32 rows (x1,y1,x2,y2,conf,cls),
  * kept_anchor[n][max_det] int32 (anchor index of each kept row), counts[n] int32.  classes: optional int32
- * list (NULL = all).  Ties in score: lower candidate index first.  ws from mgdt_nms_workspace_bytes.       */
+ * list (NULL = all).  Ties in score: lower candidate index first.  ws from mgdt_nms_workspace_bytes.
+ * best_keys: NULL, or [n][a] 64-bit keys ((0xFFFFFFFF - bits(best score)) << 32 | anchor * nc + first best class) of EVERY anchor as
+ * mgdt_detect_tail_fwd writes them next to pred: the best-class scan over pred (ops.py:225-226) is then skipped (ignored for multi_label). */
 size_t mgdt_nms_workspace_bytes(int n, int nc, int a, int multi_label, int max_nms);
 int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, float iou_thres, const int32_t* classes,
                  int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
-                 int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s);
+                 int32_t* kept_anchor, int32_t* counts, const unsigned long long* best_keys, void* ws, size_t ws_bytes, mgdt_stream s);
 
 /* ---- validator matching: DetectionValidator._process_batch, yolo/v8/detect/val.py:152-175, for a batch ----------
  * det [n][max_det][6] (x1,y1,x2,y2,conf,cls; the layout mgdt_nms_fwd writes) with ndet[n] valid rows, labels [n][max_lab][5]

@@ -73,7 +73,7 @@ PROTOTYPES = {
     'mgdt_stem2_pack': (_i, [_vp, _vp, _vp]),
     'mgdt_stem2_fwd': (_i, [VP, _i, _vp, _vp, _vp, _vp, VP, _vp]),
     'mgdt_detect_tail_supported': (_i, [_i, _i, _i, _i, _i]),
-    'mgdt_detect_tail_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _f, _i, _i, VP, _vp, _vp]),
+    'mgdt_detect_tail_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _f, _i, _i, VP, _vp, _vp, _vp]),
     'mgdt_csp_block_supported': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'mgdt_csp_block_tiles': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mgdt_csp_block_fwd': (_i, [_i, VP, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, VP, _vp, _i, _vp]),
@@ -139,7 +139,7 @@ PROTOTYPES = {
     'mgdt_ap_workspace_bytes': (_sz, [_i, _i]),
     'mgdt_ap_per_class': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     'mgdt_nms_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
-    'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'mgdt_nms_fwd': (_i, [_vp, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -17,6 +17,7 @@ struct DtArgs {
   char* feat; int fsn, fsh, fsw; uint32_t feat_bytes;
   const char* wb; const float* bb; const char* wc; const float* bc;
   float* y;
+  unsigned long long* best;            // optional [N][a_total]: NMS key of every anchor's best class
   int N, H, W, HW, c2, c3, nc, kch, nbc, units_per_img, units, a_off, a_total;
   float stride;
   FastDiv fd_w;
@@ -107,6 +108,19 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (a.best && lane < 32 && a0 + lane < a.HW) {
+      // best class of my anchor (first maximal score, ops.py:225-226) from the tile: the NMS key ((~score bits) << 32 | anchor * nc + class), so
+      // that mgdt_nms_fwd does not have to scan the 80 score rows of y again
+      const float* col = yt + 4 * DT_LD + lane;
+      float bs = col[0];
+      int bc = 0;
+      for (int c = 1; c < a.nc; ++c) {
+        const float v = col[c * DT_LD];
+        if (v > bs) { bs = v; bc = c; }
+      }
+      const unsigned an = (unsigned)(a.a_off + a0 + lane);
+      a.best[(size_t)n * a.a_total + an] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(bs)) << 32) | (unsigned long long)(an * (unsigned)a.nc + (unsigned)bc);
+    }
     float* yo = a.y + (size_t)n * (4 + a.nc) * a.a_total + a.a_off + a0;
     if (a0 + 32 <= a.HW && ((a.a_off + a0) & 3) == 0 && (a.a_total & 3) == 0 && ((uintptr_t)a.y & 15) == 0) {
       // 16-byte stores: lane = (row of 8, 4 consecutive anchors) - a quarter of the store instructions of the 4-byte form, which was store-issue bound
@@ -136,7 +150,7 @@ extern "C" int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, i
 }
 
 extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
-                                    float stride, int a_off, int a_total, const mgdt_view* feat, float* y, mgdt_stream s) {
+                                    float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys, mgdt_stream s) {
   if (!view_ok(tb) || !view_ok(tc) || !view_ok(feat) || !wb || !bb || !wc || !bc || !y) MGDT_FAIL(MGDT_BAD_ARG, "detect_tail: null/empty argument");
   if (!mgdt_detect_tail_supported(tb->c, tc->c, nc, 4, MGDT_BF16)) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: c2=%d c3=%d nc=%d not covered", tb->c, tc->c, nc);
   if (feat->c != 16 + nc || tb->n != tc->n || tb->h != tc->h || tb->w != tc->w || feat->n != tb->n || feat->h != tb->h || feat->w != tb->w ||
@@ -156,7 +170,7 @@ extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, co
   bind(feat, &fp, &a.fsn, &a.fsh, &a.fsw, &a.feat_bytes, 4);
   if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: views must be 16-byte aligned NHWC (sc == 1) below 2 GiB");
   a.feat = (char*)fp;
-  a.wb = (const char*)wb; a.bb = bb; a.wc = (const char*)wc; a.bc = bc; a.y = y;
+  a.wb = (const char*)wb; a.bb = bb; a.wc = (const char*)wc; a.bc = bc; a.y = y; a.best = best_keys;
   a.N = tb->n; a.H = tb->h; a.W = tb->w; a.HW = tb->h * tb->w; a.c2 = tb->c; a.c3 = tc->c; a.nc = nc;
   a.kch = cdiv(tc->c, 32); a.nbc = cdiv(nc, 16);
   a.units_per_img = cdiv(a.HW, 32); a.units = a.N * a.units_per_img;

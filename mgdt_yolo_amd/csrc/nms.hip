@@ -1,12 +1,16 @@
 // Batched NMS, one workgroup per image, no host round trip (the reference loops over images in Python and
 // calls ~10 small ops + torchvision.ops.nms per image: yolo/utils/ops.py:199-264).
 //
-//   1. candidate predicate straight from pred[n][4+nc][a] (score > conf, best-class or multi-label, class filter)
-//   2. exact top-`max_nms` selection by MSD radix select on the 64-bit key (descending score, ascending
-//      candidate id = anchor*nc + cls)  -> deterministic tie rule "lower candidate index first"
-//   3. bitonic sort of the selected keys (LDS when <= 16384 keys, else an L2-resident global buffer)
-//   4. greedy suppression by one wavefront, 64 sorted candidates per step: every lane tests its box against
-//      the kept list (LDS broadcast reads), survivors are resolved inside the chunk with ballot + shuffles.
+//   1. candidate predicate straight from pred[n][4+nc][a] (score > conf, best-class or multi-label, class filter); the best class per
+//      anchor comes from the Detect tail kernel when it ran (`best_keys`: it has every score in registers anyway), else from nms_best_kernel
+//   2. the candidates are taken in SEGMENTS of descending score (<= 1024 keys first, then <= 4096, ...): a 2048-bin histogram of the
+//      scores (one LDS pass + one scan) gives the score edge whose upper side holds at most that many keys - an exact top set, no
+//      multi-pass radix select; the MSD radix select on the 64-bit key (descending score, ascending candidate id = anchor*nc + cls ->
+//      tie rule "lower candidate index first") remains as the fallback when one bin alone overflows a segment or max_nms cuts inside one
+//   3. bitonic sort of the segment's keys (register shuffles for <= 1024 keys, LDS up to 16384, else an L2-resident global buffer);
+//      for <= 1024 keys every thread then fetches its candidate's box once and parks it in LDS
+//   4. greedy suppression, 64 sorted candidates per step: every lane tests its box against the kept list (LDS broadcast reads),
+//      survivors are resolved inside the chunk with ballot + scalar bit operations.
 //      The scan stops at max_det kept boxes (identical to nms(...)[:max_det]).
 // IoU arithmetic is the torchvision CPU kernel's, in IEEE fp32 with FP contraction off (this file is compiled
 // with -ffp-contract=off) on boxes offset by cls*max_wh in fp32 exactly as ops.py:247-248 does, so kept indices
@@ -17,6 +21,7 @@
 
 #define NMS_THREADS 1024
 #define NMS_LDS_KEYS 16384
+#define NMS_BINS 2048
 typedef unsigned long long u64;
 
 struct NmsArgs {
@@ -30,6 +35,7 @@ struct NmsArgs {
   float* out;
   int32_t* kept_anchor;
   int32_t* counts;
+  const u64* best;  // optional [n][A]: make_key(best score, anchor*nc + best class) of every anchor, unfiltered (written by mgdt_detect_tail_fwd)
   u64* ws;          // per image: sort buffer [cap_pow2] (+ [A] best-class keys when !multi_label)
   long ws_per_image;  // in u64
   int cap_pow2;
@@ -91,6 +97,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       if (sc > a.conf && class_ok(c, a.classes, a.n_classes)) return make_key(sc, (unsigned)an * a.nc + c);
       return KEY_NONE;
     }
+    if (a.best) {                       // unfiltered best-class keys from the Detect tail: apply the candidate predicate here
+      const u64 k = a.best[(long)img * a.A + i];
+      const float sc = __uint_as_float(0xFFFFFFFFu - (unsigned)(k >> 32));
+      return (sc > a.conf && class_ok((int)((unsigned)k % (unsigned)a.nc), a.classes, a.n_classes)) ? k : KEY_NONE;
+    }
     return akeys[i];
   };
   unsigned long long T0 = wall_clock64();
@@ -113,13 +124,39 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       for (long i = tid; i < total; i += NMS_THREADS) fn(key_at(i));
     }
   };
-  // ---- count candidates
+  // ---- score histogram: bin = floor(score * NMS_BINS) (exact: a power-of-two scaling), so {bin >= T} == {score >= T / NMS_BINS} is an exact
+  // top set of the key order.  shist[b] becomes the number of candidates in bins >= b (shist[NMS_BINS] = 0); their total is the count.
+  __shared__ unsigned shist[NMS_BINS + 1];
+  __shared__ unsigned s_wsum[NMS_THREADS / 64];
+  __shared__ int s_T;
   if (tid == 0) { s_cnt = 0; s_sel = 0; }
+  for (int i = tid; i <= NMS_BINS; i += NMS_THREADS) shist[i] = 0;
+  __syncthreads();
+  for_each_key([&](u64 k) {
+    if (k != KEY_NONE) {
+      const float sc = __uint_as_float(0xFFFFFFFFu - (unsigned)(k >> 32));
+      const int bin = min(NMS_BINS - 1, (int)(sc * (float)NMS_BINS));
+      atomicAdd(&shist[bin], 1u);
+    }
+  });
   __syncthreads();
   {
-    unsigned local = 0;
-    for_each_key([&](u64 k) { local += k != KEY_NONE; });
-    atomicAdd(&s_cnt, local);
+    static_assert(NMS_BINS == 2 * NMS_THREADS, "two bins per thread");
+    const unsigned h0 = shist[2 * tid], h1 = shist[2 * tid + 1], sum = h0 + h1;
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(incl, d, 64);
+      if ((tid & 63) >= d) incl += t;
+    }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned base = 0, total_c = 0;
+    for (int w = 0; w < NMS_THREADS / 64; ++w) { const unsigned v = s_wsum[w]; if (w < (tid >> 6)) base += v; total_c += v; }
+    const unsigned below0 = base + incl - sum;            // candidates in bins < 2 * tid
+    shist[2 * tid] = total_c - below0;
+    shist[2 * tid + 1] = total_c - below0 - h0;
+    if (tid == 0) s_cnt = total_c;
   }
   __syncthreads();
   const unsigned ncand = s_cnt;
@@ -223,6 +260,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   };
 
   // ---- greedy state
+  float* cbox = (float*)(smem + (size_t)2 * NMS_THREADS * sizeof(u64));   // segment of <= 1024 keys: the candidates' boxes [5][1024] behind the two sort buffers
+  static_assert((size_t)2 * NMS_THREADS * sizeof(u64) + (size_t)5 * NMS_THREADS * sizeof(float) <= (size_t)NMS_LDS_KEYS * sizeof(u64), "candidate boxes fit the key area");
   float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
   u64* kkey = (u64*)(kb + 5 * a.max_det + (a.max_det & 1));          // key of each kept box (8-byte aligned)
   __shared__ int s_nkept;
@@ -248,16 +287,46 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   // `seg` keys are selected and sorted first (1024, then 4x more, ...) instead of all of them
   unsigned done = 0, seg = 1024;
   u64 lo_key = 0;
+  bool use_hist = true;
+  int bin_hi = NMS_BINS;
   while (done < K) {
     if (s_nkept >= md) break;                                // uniform: read after a barrier (end of the previous segment)
     unsigned long long Ta = wall_clock64();
-    const unsigned R = (K - done <= seg + seg / 2) ? K : done + seg;      // do not leave a small tail for another pass
-    const u64 hi_key = (R == ncand) ? KEY_NONE - 1 : select_rank(R);
+    // the score edge T whose upper side [T, bin_hi) holds as many keys as fit this segment; exact because bins are score intervals
+    unsigned R = 0;
+    u64 hi_key = 0;
+    bool by_hist = false;
+    if (use_hist) {
+      const unsigned base = shist[bin_hi], cap = (K - done <= seg + seg / 2) ? seg + seg / 2 : seg;
+      if (tid == 0) s_T = bin_hi;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int b = 2 * tid + e;
+        if (b < bin_hi && shist[b] - base <= cap && (b == 0 || shist[b - 1] - base > cap)) s_T = b;      // exactly one b (shist is monotone)
+      }
+      __syncthreads();
+      const int T = s_T;
+      const unsigned c = shist[T] - base;
+      __syncthreads();                                           // s_T is rewritten by the next segment
+      if (c >= 1 && done + c <= K) {
+        by_hist = true;
+        R = done + c;
+        hi_key = T == 0 ? KEY_NONE - 1 : (((u64)(0xFFFFFFFFu - __float_as_uint((float)T / (float)NMS_BINS)) << 32) | 0xFFFFFFFFull);
+        bin_hi = T;
+      }
+    }
+    if (!by_hist) {                                              // one bin overflows the segment, or max_nms cuts inside a bin: exact rank select
+      use_hist = false;
+      R = (K - done <= seg + seg / 2) ? K : done + seg;          // do not leave a small tail for another pass
+      hi_key = (R == ncand) ? KEY_NONE - 1 : select_rank(R);
+    }
     const unsigned cnt = R - done;
     unsigned np2 = 1;
     while (np2 < cnt) np2 <<= 1;
     u64* sbuf = (np2 <= NMS_LDS_KEYS) ? (u64*)smem : gbuf;
     if (tid == 0) s_sel = 0;
+    bool preloaded = false;
     __syncthreads();
     auto put = [&](u64 k) __attribute__((always_inline)) {      // wave-aggregated: one LDS atomic per wave, not per key
       const bool sel = k != KEY_NONE && k <= hi_key && (done == 0 || k > lo_key);
@@ -302,6 +371,20 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       }
       __syncthreads();                                         // the last cross-wave reads are done before smem[] is rewritten
       ((u64*)smem)[tid] = kv;
+      {
+        // every thread fetches the box of its (sorted) candidate now - 1024 independent requests in one round trip - and parks it in LDS:
+        // the greedy steps below then never wait on a dependent key -> box load (that wait was most of a step)
+        const bool valid = (unsigned)tid < cnt;
+        const unsigned cand = (unsigned)(kv & 0xFFFFFFFFu);
+        const int an = valid ? (int)(cand / (unsigned)a.nc) : 0, cls = valid ? (int)(cand % (unsigned)a.nc) : 0;
+        const float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
+        const float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;   // xywh2xyxy, ops.py:372-376
+        const float off = a.agnostic ? 0.f : (float)cls * a.max_wh;                                  // ops.py:247
+        const float bx1 = x1 + off, by1 = y1 + off, bx2 = x2 + off, by2 = y2 + off;
+        cbox[tid] = bx1; cbox[NMS_THREADS + tid] = by1; cbox[2 * NMS_THREADS + tid] = bx2; cbox[3 * NMS_THREADS + tid] = by2;
+        cbox[4 * NMS_THREADS + tid] = (bx2 - bx1) * (by2 - by1);
+      }
+      preloaded = true;
       __syncthreads();
     } else if (np2 <= NMS_LDS_KEYS) bitonic((u64*)smem, np2);
     else bitonic(gbuf, np2);
@@ -317,6 +400,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       Cand c;
       c.valid = idx < cnt;
       c.key = c.valid ? sbuf[idx] : KEY_NONE;
+      if (preloaded) {                                         // uniform
+        const unsigned i = c.valid ? idx : 0u;
+        c.bx1 = cbox[i]; c.by1 = cbox[NMS_THREADS + i]; c.bx2 = cbox[2 * NMS_THREADS + i]; c.by2 = cbox[3 * NMS_THREADS + i]; c.area = cbox[4 * NMS_THREADS + i];
+        return c;
+      }
       const unsigned cand = (unsigned)(c.key & 0xFFFFFFFFu);
       const int an = c.valid ? (int)(cand / (unsigned)a.nc) : 0, cls = c.valid ? (int)(cand % (unsigned)a.nc) : 0;
       const float cx = P[an], cy = P[(long)a.A + an], w = P[2L * a.A + an], h = P[3L * a.A + an];
@@ -415,7 +503,7 @@ extern "C" size_t mgdt_nms_workspace_bytes(int n, int nc, int a, int multi_label
 
 extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_thres, float iou_thres, const int32_t* classes,
                             int n_classes, int agnostic, int multi_label, int max_det, int max_nms, float max_wh, float* out,
-                            int32_t* kept_anchor, int32_t* counts, void* ws, size_t ws_bytes, mgdt_stream s) {
+                            int32_t* kept_anchor, int32_t* counts, const unsigned long long* best_keys, void* ws, size_t ws_bytes, mgdt_stream s) {
   if (!pred || !out || !kept_anchor || !counts || !ws) MGDT_FAIL(MGDT_BAD_ARG, "nms: null pointer");
   if (!(conf_thres >= 0.f && conf_thres <= 1.f)) MGDT_FAIL(MGDT_BAD_ARG, "Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", conf_thres);
   if (!(iou_thres >= 0.f && iou_thres <= 1.f)) MGDT_FAIL(MGDT_BAD_ARG, "Invalid IoU %g, valid values are between 0.0 and 1.0", iou_thres);
@@ -429,6 +517,7 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   g.pred = pred; g.n = n; g.nc = nc; g.A = a; g.conf = conf_thres; g.iou = iou_thres; g.classes = n_classes > 0 ? classes : nullptr;
   g.n_classes = n_classes; g.agnostic = agnostic; g.multi_label = multi_label; g.max_det = max_det; g.max_nms = max_nms;
   g.max_wh = max_wh; g.out = out; g.kept_anchor = kept_anchor; g.counts = counts; g.ws = (u64*)ws;
+  g.best = multi_label ? nullptr : (const u64*)best_keys;
   long cand = multi_label ? (long)a * nc : a;
   g.cap_pow2 = next_pow2((int)std::min<long>(cand, max_nms));
   g.ws_per_image = g.cap_pow2 + (multi_label ? 0 : a);
@@ -438,7 +527,7 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
     if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "nms: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     attr_lds = lds;
   }
-  if (!multi_label) nms_best_kernel<<<dim3(cdiv(a, 256), n), 256, 0, (hipStream_t)s>>>(g);
+  if (!multi_label && !g.best) nms_best_kernel<<<dim3(cdiv(a, 256), n), 256, 0, (hipStream_t)s>>>(g);
   nms_kernel<<<n, NMS_THREADS, lds, (hipStream_t)s>>>(g);
   MGDT_CHECK_LAUNCH("nms_fwd");
   return MGDT_OK;

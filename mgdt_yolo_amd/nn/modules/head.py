@@ -72,6 +72,7 @@ class Detect(HipModule):
             strides = self._cached('stride_list', [self.stride], lambda: [float(v) for v in self.stride.tolist()])  # host copy, no sync per call
             a_total = sum(t.shape[2] * t.shape[3] for t in x)
             y = torch.empty(shape[0], 4 + self.nc, a_total, dtype=torch.float32, device=x[0].device)
+            best = torch.empty(shape[0], a_total, dtype=torch.int64, device=x[0].device)      # NMS keys of the anchors' best classes (detect tail)
         decoded = [False] * self.nl
         for i in range(self.nl):
             xi = x[i]
@@ -92,7 +93,7 @@ class Detect(HipModule):
                                    lambda c=self.cv2[i][2]: ops.PackedConv(c.weight, c.bias, None, 1, feat.dtype))
                 pkc = self._cached((id(self.cv3[i][2]), feat.dtype), [self.cv3[i][2].weight, self.cv3[i][2].bias],
                                    lambda c=self.cv3[i][2]: ops.PackedConv(c.weight, c.bias, None, 1, feat.dtype))
-                ops.detect_tail(tb, tc, pkb, pkc, self.nc, strides[i], a_off, feat, y)
+                ops.detect_tail(tb, tc, pkb, pkc, self.nc, strides[i], a_off, feat, y, best)
                 decoded[i] = True
             else:
                 _HeadConv.run(self, self.cv2[i][2], tb, feat[:, :r4])
@@ -113,6 +114,8 @@ class Detect(HipModule):
             if not decoded[i]:
                 ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
+        if all(decoded):
+            ops.attach_best_keys(y, best)        # every level went through the tail kernel: non_max_suppression(y) skips its best-class scan
         return y if self.export else (y, x)
 
     def _merged_first(self, i, xi, dt, xq=None):
@@ -404,6 +407,8 @@ class TOODHead(Detect):
         for i, f in enumerate(x):
             ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
+        if all(decoded):
+            ops.attach_best_keys(y, best)        # every level went through the tail kernel: non_max_suppression(y) skips its best-class scan
         return y if self.export else (y, x)
 
     def _bias_conv_bwd(self, conv, x, g, pad_to=None, accumulate=False):

@@ -668,17 +668,35 @@ def detect_tail_supported(tb, tc, nc, reg_max, dtype):
                 L.lib().mgdt_detect_tail_supported(tb.shape[1], tc.shape[1], int(nc), int(reg_max), dtype_code(dtype)))
 
 
-def detect_tail(tb, tc, pkb, pkc, nc, stride, a_off, feat, y):
-    """mgdt_detect_tail_fwd: final 1x1 convs of both branches + raw map `feat` + decode into y."""
+def detect_tail(tb, tc, pkb, pkc, nc, stride, a_off, feat, y, best=None):
+    """mgdt_detect_tail_fwd: final 1x1 convs of both branches + raw map `feat` + decode into y (+ per-anchor best-class NMS keys into `best`,
+    int64 [B][A], when given)."""
     if _PROF is not None:
         b, _, h, w = tb.shape
         _META['detect_tail_fwd'] = dict(shape=(b, tb.shape[1] + tc.shape[1], h, w, 16 + nc, 1, 1), flops=2.0 * b * h * w * (tb.shape[1] * 16 + tc.shape[1] * nc),
                                         bytes=float((tb.numel() + tc.numel() + feat.numel()) * 2 + b * (4 + nc) * h * w * 4))
     _launch('detect_tail_fwd', 'mgdt_detect_tail_fwd', vp(tb), vp(tc), ptr(pkb.w), ptr(pkb.bias), ptr(pkc.w), ptr(pkc.bias), int(nc), float(stride), int(a_off),
-            y.shape[2], vp(feat), ptr(y), stream())
+            y.shape[2], vp(feat), ptr(y), ptr(best), stream())
 
 
 # ------------------------------------------------------------------ NMS
+NMS_USE_BEST_KEYS = True      # tests flip this to compare against the scan of the score rows (nms_best_kernel)
+
+
+def attach_best_keys(y, best):
+    """The Detect tail kernel left the NMS key of every anchor's best class in `best`; remember it on the prediction tensor together with
+    the tensor's version, so that `nms(y)` can skip its own scan over the nc score rows as long as nobody wrote into y since."""
+    y._mgdt_best = (best, y._version)
+
+
+def _best_keys_of(pred, b, a):
+    bk = getattr(pred, '_mgdt_best', None)
+    if not NMS_USE_BEST_KEYS or bk is None:
+        return None
+    best, ver = bk
+    if ver != pred._version or best.shape != (b, a) or best.dtype != torch.int64 or best.device != pred.device or not best.is_contiguous():
+        return None
+    return best
 def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, max_nms, max_wh):
     """pred (B, 4+nc, A) fp32 cuda contiguous -> (out [B,max_det,6], kept_anchor [B,max_det] int32, counts [B] int32)."""
     _need_gpu(pred)
@@ -697,8 +715,9 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det, ma
     cls_t = None
     if classes is not None:
         cls_t = torch.as_tensor(list(classes), dtype=torch.int32).to(pred.device)
+    best = None if ml else _best_keys_of(pred, b, a)
     _launch('nms_fwd', 'mgdt_nms_fwd', ptr(pred), b, nc, a, float(conf_thres), float(iou_thres), ptr(cls_t), 0 if cls_t is None else cls_t.numel(),
-                             int(bool(agnostic)), ml, max_det, max_nms, float(max_wh), ptr(out), ptr(kept), ptr(counts), ptr(ws),
+                             int(bool(agnostic)), ml, max_det, max_nms, float(max_wh), ptr(out), ptr(kept), ptr(counts), ptr(best), ptr(ws),
                              ws_bytes, stream())
     return out, kept, counts
 

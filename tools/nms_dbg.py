@@ -14,8 +14,10 @@ lib = L.lib()
 wsb = lib.mgdt_nms_workspace_bytes(b, ch - 4, a, 0, 30000)
 ws = torch.zeros(wsb // 8, dtype=torch.int64, device='cuda')
 out = torch.zeros(b, 300, 6, device='cuda'); kept = torch.zeros(b, 300, dtype=torch.int32, device='cuda'); cnt = torch.zeros(b, dtype=torch.int32, device='cuda')
+best = ops._best_keys_of(y, b, a) if os.environ.get('NMS_BEST', '1') == '1' else None
+print('best keys from the detect tail:', best is not None)
 for _ in range(2):
-    L.check(lib.mgdt_nms_fwd(ops.ptr(y), b, ch - 4, a, 0.25, 0.7, None, 0, 0, 0, 300, 30000, 7680.0, ops.ptr(out), ops.ptr(kept), ops.ptr(cnt), ops.ptr(ws), wsb, ops.stream()))
+    L.check(lib.mgdt_nms_fwd(ops.ptr(y), b, ch - 4, a, 0.25, 0.7, None, 0, 0, 0, 300, 30000, 7680.0, ops.ptr(out), ops.ptr(kept), ops.ptr(cnt), ops.ptr(best), ops.ptr(ws), wsb, ops.stream()))
 torch.cuda.synchronize()
 per = wsb // 8 // b
 for i in (0, 1, 31):
