@@ -106,6 +106,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   };
   unsigned long long T0 = wall_clock64();
   unsigned long long Tsel = 0, Tsort = 0, Tgreedy = 0;
+  long long Cg[6] = {0, 0, 0, 0, 0, 0};      // MGDT_NMS_DBG: cycles of the greedy step's parts (kept list, chunk matrix, barrier, walk, barrier) + steps
   // every pass over the candidates (count, the radix-select passes, the compactions) re-reads the same keys: when they fit, a thread keeps
   // its share (flat indices tid, tid + 1024, ...) in registers for the whole kernel
   constexpr int KPT = 8;
@@ -262,12 +263,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   // ---- greedy state
   float* cbox = (float*)(smem + (size_t)2 * NMS_THREADS * sizeof(u64));   // segment of <= 1024 keys: the candidates' boxes [5][1024] behind the two sort buffers
   static_assert((size_t)2 * NMS_THREADS * sizeof(u64) + (size_t)5 * NMS_THREADS * sizeof(float) <= (size_t)NMS_LDS_KEYS * sizeof(u64), "candidate boxes fit the key area");
-  float* kb = (float*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));   // kept boxes (offset): [5][max_det] = x1,y1,x2,y2,area
-  u64* kkey = (u64*)(kb + 5 * a.max_det + (a.max_det & 1));          // key of each kept box (8-byte aligned)
+  f32x4* kb4 = (f32x4*)(smem + (size_t)NMS_LDS_KEYS * sizeof(u64));    // kept boxes (class-offset): (x1, y1, x2, y2) - one 16-byte broadcast read per test
+  float* karea = (float*)(kb4 + a.max_det);                              // their areas: read only by the rare exact IoU test
+  u64* kkey = (u64*)(karea + a.max_det + (a.max_det & 1));              // key of each kept box (8-byte aligned)
   __shared__ int s_nkept;
-  __shared__ unsigned s_sup[2], s_sb[64][2];
+  __shared__ unsigned s_sup[2];
+  __shared__ unsigned s_row[64][2];                          // chunk-local suppression, row form: bit j of row i = the earlier candidate j suppresses i
   if (tid == 0) { s_nkept = 0; s_sup[0] = 0; s_sup[1] = 0; }
-  if (tid < 64) { s_sb[tid][0] = 0; s_sb[tid][1] = 0; }
+  if (tid < 64) { s_row[tid][0] = 0; s_row[tid][1] = 0; }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int md = a.max_det;
@@ -279,8 +282,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     const float inter = iw * ih;
     return inter / (karea + area - inter) > a.iou;
   };
-  auto suppressed_by = [&](int k, float bx1, float by1, float bx2, float by2, float area) -> bool {
-    return overlaps(kb[k], kb[md + k], kb[2 * md + k], kb[3 * md + k], kb[4 * md + k], bx1, by1, bx2, by2, area);
+  // Cheap exact-superset pre-test: iw > 0 && ih > 0 implies kx1 < bx2 && bx1 < kx2 && ky1 < by2 && by1 < ky2 (four compares, no arithmetic).
+  // Boxes of different classes are max_wh apart, so almost every pair fails it; the IoU arithmetic runs only when some lane of the wave passes.
+  auto may_overlap = [&](float kx1, float ky1, float kx2, float ky2, float bx1, float by1, float bx2, float by2) -> bool {
+    return kx1 < bx2 && bx1 < kx2 && ky1 < by2 && by1 < ky2;
   };
 
   // ---- segments: the scan stops at max_det kept boxes, which usually happens within the first few hundred candidates, so only the best
@@ -419,50 +424,102 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
       const int nk = s_nkept;             // uniform: written by wave 0 before the barrier that ended the previous step
       if (nk >= md) break;
       Cand nxt = load_cand(base + 64 + (unsigned)lane);      // in flight during this step
+      long long c0 = a.dbg ? clock64() : 0;
       bool sup = false;
-      for (int k = wave; k < nk; k += NMS_THREADS / 64)
-        if (suppressed_by(k, cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) sup = true;
-      unsigned sb_lo = 0, sb_hi = 0;
+      // kept boxes k = wave, wave + 16, ...: four broadcast reads in flight per round (one dependent LDS round trip per box was most of this loop)
+      for (int k0 = wave; k0 < nk; k0 += 4 * (NMS_THREADS / 64)) {
+        f32x4 q[4];
+        bool hit[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = wave * 4 + t;                          // uniform
-        const float jx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx1), j));
-        const float jy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by1), j));
-        const float jx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx2), j));
-        const float jy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by2), j));
-        const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.area), j));
-        // kept box = the earlier candidate j, tested box = this lane's: the argument order of the serial scan
-        if (j < lane && overlaps(jx1, jy1, jx2, jy2, jar, cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) {
-          if (j < 32) sb_lo |= 1u << j; else sb_hi |= 1u << (j - 32);
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * (NMS_THREADS / 64);
+          q[u] = kb4[k < nk ? k : k0];
+        }
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          hit[u] = k0 + u * (NMS_THREADS / 64) < nk && may_overlap(q[u][0], q[u][1], q[u][2], q[u][3], cur.bx1, cur.by1, cur.bx2, cur.by2);
+          any |= hit[u];
+        }
+        if (__ballot(any)) {                                   // rare
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (hit[u] && overlaps(q[u][0], q[u][1], q[u][2], q[u][3], karea[k0 + u * (NMS_THREADS / 64)], cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) sup = true;
         }
       }
-      if (sb_lo) atomicOr(&s_sb[lane][0], sb_lo);
-      if (sb_hi) atomicOr(&s_sb[lane][1], sb_hi);
+      long long c1 = a.dbg ? clock64() : 0;
+      // chunk-local matrix, row form: bit j of a lane's row = the earlier candidate j of the chunk suppresses this lane's candidate.  This wave
+      // tests the columns j = 4 * wave .. 4 * wave + 3; the (rare) set bits are OR-ed into the lane's row in LDS.
+      {
+        unsigned rlo = 0, rhi = 0;
+        float jb[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int j = wave * 4 + t;                        // uniform
+          jb[t][0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx1), j));
+          jb[t][1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by1), j));
+          jb[t][2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.bx2), j));
+          jb[t][3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.by2), j));
+        }
+        bool hit[4], any = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          hit[t] = wave * 4 + t < lane && may_overlap(jb[t][0], jb[t][1], jb[t][2], jb[t][3], cur.bx1, cur.by1, cur.bx2, cur.by2);
+          any |= hit[t];
+        }
+        if (__ballot(any)) {                                   // rare
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int j = wave * 4 + t;
+            const float jar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.area), j));
+            // kept box = the earlier candidate j, tested box = this lane's: the argument order of the serial scan
+            if (hit[t] && overlaps(jb[t][0], jb[t][1], jb[t][2], jb[t][3], jar, cur.bx1, cur.by1, cur.bx2, cur.by2, cur.area)) {
+              if (j < 32) rlo |= 1u << j; else rhi |= 1u << (j - 32);
+            }
+          }
+          if (rlo) atomicOr(&s_row[lane][0], rlo);
+          if (rhi) atomicOr(&s_row[lane][1], rhi);
+        }
+      }
       {
         const u64 m = __ballot(sup);
         if (lane == 0 && m) { atomicOr(&s_sup[0], (unsigned)m); atomicOr(&s_sup[1], (unsigned)(m >> 32)); }
       }
+      long long c2 = a.dbg ? clock64() : 0;
       __syncthreads();
+      long long c3 = a.dbg ? clock64() : 0;
       if (wave == 0) {
         const u64 supm = ((u64)s_sup[1] << 32) | s_sup[0];
-        const unsigned mlo = s_sb[lane][0], mhi = s_sb[lane][1];      // earlier candidates of the chunk that suppress this one
-        u64 am = __ballot(cur.valid) & ~supm, keep = 0;
-        int room = md - nk;
-        while (am && room > 0) {                               // candidate i (in score order) survives iff no kept earlier one suppresses it
-          const int i = __ffsll((long long)am) - 1;
-          am &= ~(1ull << i);
-          const u64 by = ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mlo, i);
-          if ((by & keep) == 0) { keep |= 1ull << i; --room; }
+        const u64 row = ((u64)s_row[lane][1] << 32) | s_row[lane][0];     // earlier candidates of the chunk that suppress this lane's
+        const u64 alive = __ballot(cur.valid) & ~supm;
+        // greedy rule inside the chunk: candidate i is kept iff it is alive and no KEPT earlier candidate suppresses it.  That recursion has
+        // exactly one solution (fixed by induction over i) and iterating keep <- alive & ~(row hits keep) from keep = alive reaches it: after t
+        // rounds the first t candidates are final, and a round that changes nothing is the solution.  Rows are almost always empty, so one
+        // or two lane-parallel rounds replace a 64-step scalar walk.
+        u64 keep = alive;
+        for (int it = 0; it < 64; ++it) {
+          const u64 nk_ = __ballot(((alive >> lane) & 1ull) && (row & keep) == 0);
+          if (nk_ == keep) break;
+          keep = nk_;
+        }
+        const int room = md - nk;                              // only the first `room` kept candidates (in score order) fit
+        if (__popcll(keep) > room) {
+          u64 k2 = keep;
+          for (int c = 0; c < room; ++c) k2 &= k2 - 1;         // clear the lowest `room` set bits: what remains is the overflow
+          keep &= ~k2;
         }
         if ((keep >> lane) & 1ull) {
           const int slot = nk + __popcll(keep & ((1ull << lane) - 1ull));
-          kb[slot] = cur.bx1; kb[md + slot] = cur.by1; kb[2 * md + slot] = cur.bx2; kb[3 * md + slot] = cur.by2; kb[4 * md + slot] = cur.area;
+          kb4[slot] = f32x4{cur.bx1, cur.by1, cur.bx2, cur.by2};
+          karea[slot] = cur.area;
           kkey[slot] = cur.key;
         }
-        s_sb[lane][0] = 0; s_sb[lane][1] = 0;
+        s_row[lane][0] = 0; s_row[lane][1] = 0;
         if (lane == 0) { s_sup[0] = 0; s_sup[1] = 0; s_nkept = nk + (int)__popcll(keep); }
       }
+      long long c4 = a.dbg ? clock64() : 0;
       __syncthreads();
+      if (a.dbg) { long long c5 = clock64(); Cg[0] += c1 - c0; Cg[1] += c2 - c1; Cg[2] += c3 - c2; Cg[3] += c4 - c3; Cg[4] += c5 - c4; Cg[5] += 1; }
       cur = nxt;
     }
     __syncthreads();
@@ -486,7 +543,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     a.kept_anchor[(long)img * md + t] = an;
   }
   if (tid == 0) a.counts[img] = s_nkept;
-  if (tid == 0 && a.dbg) { unsigned long long T4 = wall_clock64(); gbuf[0] = T4 - T0; gbuf[1] = Tsel; gbuf[2] = Tsort; gbuf[3] = Tgreedy; gbuf[4] = K; }
+  if (tid == 0 && a.dbg) { unsigned long long T4 = wall_clock64(); gbuf[0] = T4 - T0; gbuf[1] = Tsel; gbuf[2] = Tsort; gbuf[3] = Tgreedy; gbuf[4] = K; for (int i = 0; i < 6; ++i) gbuf[5 + i] = (u64)Cg[i]; }
 }
 
 static inline int next_pow2(int v) {
@@ -510,7 +567,7 @@ extern "C" int mgdt_nms_fwd(const float* pred, int n, int nc, int a, float conf_
   if (n < 1 || nc < 1 || a < 1 || max_det < 1 || max_nms < 1 || (long)a * nc > 0x7fffffffL) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: n=%d nc=%d a=%d max_det=%d", n, nc, a, max_det);
   multi_label = multi_label && nc > 1;   // ops.py:196
   if (ws_bytes < mgdt_nms_workspace_bytes(n, nc, a, multi_label, max_nms)) MGDT_FAIL(MGDT_WORKSPACE, "nms: workspace too small");
-  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)(5 * max_det + (max_det & 1)) * sizeof(float) + (size_t)max_det * sizeof(u64);
+  size_t lds = (size_t)NMS_LDS_KEYS * sizeof(u64) + (size_t)(5 * max_det + (max_det & 1)) * sizeof(float) + (size_t)max_det * sizeof(u64);   // keys | kept float4 + area | kept keys
   if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "nms: max_det=%d too large for the LDS kept list", max_det);
   NmsArgs g;
   g.dbg = getenv("MGDT_NMS_DBG") != nullptr;

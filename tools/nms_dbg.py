@@ -21,4 +21,5 @@ for _ in range(2):
 torch.cuda.synchronize()
 per = wsb // 8 // b
 for i in (0, 1, 31):
-    print('img', i, 'ticks(10ns) total / select+compact / sort / greedy, K:', ws[i * per:i * per + 5].tolist(), 'kept', int(cnt[i]))
+    print('img', i, 'ticks(10ns) total / select+compact / sort / greedy, K:', ws[i * per:i * per + 5].tolist(), 'kept', int(cnt[i]),
+          '| greedy cycles kept-list / chunk matrix / barrier / walk / barrier, steps:', ws[i * per + 5:i * per + 11].tolist())
