@@ -105,6 +105,18 @@ size_t mgdt_cnx_mlp_workspace_bytes(int n, int h, int w, int c);
 int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packed, const float* gamma, const float* beta, void* ws,
                      const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- a whole ConvNeXtV2 block in ONE launch, bf16 inference (nn/modules/convnextv2.py:48-77): dw 7x7 + bias + LayerNorm, pwconv1 + GELU with the
+ * 4c-wide hidden tile kept in registers, GRN (the workgroups of an image meet at a per-image barrier for sum_hw h^2), pwconv2 + residual.
+ * x, y: N x H x W x c NHWC views (y may not alias x: neighbouring tiles read x's halo), dw_w49c [49][c] fp32 (tap-major), packed: the blob of
+ * mgdt_cnx_mlp_pack.  ws (mgdt_cnx_block_workspace_bytes, 16-byte aligned): its first 4096 bytes are arrival counters that MUST BE ZERO at the
+ * first call and belong to this function from then on (they advance by a multiple of the tile count per call, so hipGraph replays need no
+ * reset).  mgdt_cnx_block_supported: c in {32, 64, 96}, bf16, a tile decomposition with at most as many tiles per image as the chip has
+ * compute units (every workgroup of a launch is resident at once; larger batches run as several launches of whole images). */
+int mgdt_cnx_block_supported(int n, int h, int w, int c, int dtype);
+size_t mgdt_cnx_block_workspace_bytes(int n, int h, int w, int c);
+int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, const float* dw_b, const float* ln_w, const float* ln_b, float eps, const void* packed,
+                       const float* gamma, const float* beta, void* ws, size_t ws_bytes, const mgdt_view* y, int dtype, mgdt_stream s);
+
 /* ---- layers 0 and 1 of every YOLOv8 graph (Conv 3->16 k3 s2, Conv 16->32 k3 s2, both + BN + SiLU; models/v8/*.yaml rows 0-1) in one
  * launch, bf16 path: the image patch is staged in LDS with 16-byte row loads, layer 0 runs on MFMA out of LDS, its map never leaves the
  * CU.  x: N x 3 x H x W NCHW image (any strides), x_dtype MGDT_BF16 / MGDT_F32 / MGDT_U8 (u8 is divided by 255 like

@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "conv_igemm_kernel.h"
+#include "mlp_common.h"
 
 struct MlpArgs {
   const char* t; int tsn, tsh, tsw; uint32_t t_bytes;
@@ -32,31 +33,6 @@ template <typename T> struct MlpGeom {
 // blob layout: W1 [KC1][NB1][64][PE] | W2 [KC2][NB2][64][PE] | b1 [4C] f32 | b2 [NB2*16] f32
 static inline size_t mlp_w1_bytes(int kc1) { return (size_t)kc1 * (kc1 * 8) * 1024; }          // NB1 = 4C/16 = 8*KC1 (C = 32*KC1)
 static inline size_t mlp_w2_bytes(int kc1) { return (size_t)(4 * kc1) * (2 * kc1) * 1024; }    // KC2 = 4*KC1, NB2 = 2*KC1
-
-__device__ __forceinline__ float row_sum16(float v) {   // sum over the 16 lanes of a row; valid in lane 15 of the row
-  int x;
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true); v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true); v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true); v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true); v += __builtin_bit_cast(float, x);
-  return v;
-}
-
-// GELU = v * Phi(v) = max(v, 0) - |v| * Phi(-|v|), with the normal tail through ONE transcendental:
-// log2 Phi(-a) is smooth, a degree-7 polynomial (least-squares fit on [0, 6.5], beyond that |v| * tail < 3e-10) reproduces the exact
-// erf GELU to 6e-7 absolute - fp32 rounding level, far below the bf16 resolution the hidden map is rounded to.  libm's erff costs
-// ~4x more VALU time and the two passes were bound by it (2 * 4C GELUs per pixel).
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float a = fminf(fabsf(v), 6.5f);
-  float p = fmaf(a, -1.80876783e-06f, 6.10729982e-05f);
-  p = fmaf(a, p, -9.26397088e-04f);
-  p = fmaf(a, p, 8.49198863e-03f);
-  p = fmaf(a, p, -5.39291965e-02f);
-  p = fmaf(a, p, -4.58491793e-01f);
-  p = fmaf(a, p, -1.15124323e+00f);
-  p = fmaf(a, p, -9.99995048e-01f);
-  return fmaf(-fabsf(v), __builtin_amdgcn_exp2f(p), fmaxf(v, 0.f));
-}
 
 constexpr int MLP_THREADS = 1024;   // 16 waves: the passes are VALU-bound (GELU), so fill all four SIMDs four deep
 

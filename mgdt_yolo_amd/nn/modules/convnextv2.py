@@ -1,5 +1,6 @@
-"""ConvNeXtV2_Block (reference nn/modules/convnextv2.py:48-77) on NHWC.  bf16 inference with dim in {32, 64, 96}: dw7x7+LN, then
-the whole MLP with the 4C hidden map kept on chip (mgdt_cnx_mlp_fwd).  Otherwise three fused HIP steps:
+"""ConvNeXtV2_Block (reference nn/modules/convnextv2.py:48-77) on NHWC.  bf16 inference with dim in {32, 64, 96}: the whole block in ONE
+launch (mgdt_cnx_block_fwd) when its tiles fit the chip, else dw7x7+LN, then the whole MLP with the 4C hidden map kept on chip
+(mgdt_cnx_mlp_fwd).  Otherwise three fused HIP steps:
    1. dw7x7 + bias + LayerNorm(eps 1e-6)                       (mgdt_dwconv7_ln_fwd)
    2. pwconv1 (Linear C->4C) + exact GELU as a 1x1 MFMA conv   (mgdt_conv2d_fwd)
    3. GRN statistics -> per-(image,channel) scale, folded with beta into pwconv2's input affine, + residual
@@ -83,6 +84,13 @@ class ConvNeXtV2_Block(HipModule):
             pw1_raw = self._cached(('pw1raw', dt), [self.pwconv1.weight],
                                    lambda: ops.PackedConv(self.pwconv1.weight.detach().reshape(4 * dim, dim, 1, 1), None, None, 1, dt))
             return self._train_fwd(x, dw, pw1_raw, pw2, gb)
+        if ops.cnx_mlp_supported(dim, dt) and ops.cnx_block_supported(x, dt):
+            # the whole block in one launch: the normalised map stays in LDS, the hidden 4C tile in registers (mgdt_cnx_block_fwd)
+            mlp = self._cached(('mlp', dt), [self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias],
+                               lambda: ops.PackedCnxMlp(self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias, dt))
+            vec = self._cached('dwln', [self.dwconv.bias, self.norm.weight, self.norm.bias],
+                               lambda: tuple(t.detach().float().contiguous() for t in (self.dwconv.bias, self.norm.weight, self.norm.bias)))
+            return ops.cnx_block(x, dw, vec[0], vec[1], vec[2], self.norm.eps, mlp, gb[0], gb[1])
         t = ops.dwconv7_ln(x, dw, self.dwconv.bias.detach().float(), self.norm.weight.detach().float(), self.norm.bias.detach().float(),
                            self.norm.eps)
         if ops.cnx_mlp_supported(dim, dt):     # hidden 4C map never leaves the chip

@@ -407,8 +407,6 @@ class TOODHead(Detect):
         for i, f in enumerate(x):
             ops.detect_decode(f, self.reg_max, self.nc, strides[i], a_off, y)
             a_off += f.shape[2] * f.shape[3]
-        if all(decoded):
-            ops.attach_best_keys(y, best)        # every level went through the tail kernel: non_max_suppression(y) skips its best-class scan
         return y if self.export else (y, x)
 
     def _bias_conv_bwd(self, conv, x, g, pad_to=None, accumulate=False):

@@ -500,6 +500,35 @@ def cnx_mlp(t, res, pk, gamma, beta, out=None):
     return out
 
 
+FUSED_CNX_BLOCK = True  # tests flip this to compare against dwconv7_ln + the two-pass MLP
+_CNX_WS = {}            # (device, bytes) -> zero-initialised workspace of mgdt_cnx_block_fwd (its arrival counters live across calls)
+
+
+def cnx_block_supported(x, dtype):
+    b, c, h, w = x.shape
+    return bool(FUSED_CNX_BLOCK and x.dtype == dtype and is_nhwc(x) and L.lib().mgdt_cnx_block_supported(b, h, w, c, dtype_code(dtype)))
+
+
+def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None):
+    """out = x + pwconv2(GRN(gelu(pwconv1(LayerNorm(dwconv7x7(x)))))) in one launch (mgdt_cnx_block_fwd)."""
+    b, c, h, w = x.shape
+    out = like(x) if out is None else out
+    if out.data_ptr() == x.data_ptr():
+        raise RuntimeError('cnx_block: the output may not alias the input (tiles read their neighbours\' halo)')
+    nbytes = L.lib().mgdt_cnx_block_workspace_bytes(b, h, w, c)
+    key = (x.device, nbytes)
+    ws = _CNX_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('cnx_block: run the model once before capturing it into a graph (the kernel\'s arrival counters are allocated and zeroed on first use)')
+        ws = _CNX_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+    if _PROF is not None:
+        _META['cnx_block_fwd'] = dict(shape=(b, c, h, w, c, 7, 1), flops=2.0 * b * h * w * c * (4 * c * 2 + 49), bytes=float(2 * b * h * w * c * x.element_size()))
+    _launch('cnx_block_fwd', 'mgdt_cnx_block_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), float(eps), ptr(pk.blob), ptr(gamma), ptr(beta), ptr(ws), nbytes,
+            vp(out), dtype_code(x.dtype), stream())
+    return out
+
+
 FUSED_INJECT = True     # tests flip this to compare against conv + inject
 
 

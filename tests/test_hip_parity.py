@@ -98,6 +98,39 @@ def test_convnext_fused_mlp_matches_three_launch_chain(dim, hw):
     assert (y_fused - y32).abs().max().item() < 3e-2 * scale
 
 
+@pytest.mark.parametrize('b,dim,hw', [(32, 96, (40, 40)), (3, 96, (23, 17)), (2, 64, (13, 9)), (5, 32, (7, 21)), (70, 96, (20, 20)), (1, 96, (80, 80)), (2, 96, (5, 3))])
+def test_convnext_block_single_launch_matches_the_launch_chain(b, dim, hw):
+    """mgdt_cnx_block_fwd (dw7x7 + LayerNorm + pwconv1 + GELU + GRN + pwconv2 + residual in ONE launch; the workgroups of an image meet at a
+    per-image barrier for the GRN statistic) against the three-launch chain it replaces (mgdt_dwconv7_ln_fwd + the two passes of
+    mgdt_cnx_mlp_fwd) and against the fp32 chain.  Both bf16 forms round the normalised map and the hidden map to bf16 at the same points;
+    what differs is fp32 summation order (depth-wise taps, GRN partial sums, pwconv2's K loop) -> agreement at bf16 resolution (2e-2 of the
+    output's largest magnitude).  Shapes: the bench shape, maps that do not divide into tiles, one tile per image, a batch that needs
+    several launches (70 images x 4 tiles > 256 compute units), a map of 32 tiles per image.  Called three times: the arrival counters
+    persist across calls (hipGraph replays never reset them)."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import ConvNeXtV2_Block
+    m = seed_state_dict_(ConvNeXtV2_Block(dim), 3).eval().to(DEV)
+    with torch.no_grad():
+        m.grn.gamma.normal_(0, 0.5)
+        m.grn.beta.normal_(0, 0.5)
+    x = torch.randn(b, dim, *hw, generator=torch.Generator().manual_seed(5)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ops.cnx_block_supported(x, torch.bfloat16)
+    with torch.no_grad():
+        ys = [m(x).float() for _ in range(3)]
+        ops.FUSED_CNX_BLOCK = False
+        try:
+            y_chain = m(x).float()
+        finally:
+            ops.FUSED_CNX_BLOCK = True
+        y32 = m(x.float()).float()      # fp32 path (always the chain) as the yardstick
+    assert torch.isfinite(ys[0]).all()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), 'the kernel must be deterministic and replayable'
+    scale = y32.abs().max().item()
+    e_chain, e32 = (ys[0] - y_chain).abs().max().item(), (ys[0] - y32).abs().max().item()
+    print(f'cnx_block {b}x{dim}x{hw}: vs chain {e_chain / scale:.2e}, vs fp32 {e32 / scale:.2e} of max |y| = {scale:.2f}')
+    assert e_chain < 2e-2 * scale and e32 < 3e-2 * scale
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('b,c,hw', [(32, 96, (40, 40)), (3, 96, (23, 17)), (2, 64, (13, 9)), (1, 32, (7, 21)), (2, 160, (12, 10))],
                          ids=['bench-tile10', 'odd-96', 'c64', 'c32', 'c160-tiled'])

@@ -34,7 +34,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     v = _lib.View(None, 1, 8, 8, 8, 512, 64, 8, 1)
     assert lib.mgdt_conv2d_fwd(v, None, None, None, None, None, 3, 1, 1, None, None, v, 0, None) == -4    # null pointers
     assert b'null' in lib.mgdt_last_error()
-    assert lib.mgdt_nms_fwd(None, 1, 1, 1, 0.5, 0.5, None, 0, 0, 0, 1, 1, 1.0, None, None, None, None, 0, None) == -4
+    assert lib.mgdt_nms_fwd(None, 1, 1, 1, 0.5, 0.5, None, 0, 0, 0, 1, 1, 1.0, None, None, None, None, None, 0, None) == -4
 
 
 @pytest.mark.parametrize('name', [n for n in CONFIGS if not n.endswith('_hidc128')])     # *_hidc128: our own s-scale variant, no reference file
