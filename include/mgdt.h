@@ -108,9 +108,9 @@ int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packe
 /* ---- a whole ConvNeXtV2 block in ONE launch, bf16 inference (nn/modules/convnextv2.py:48-77): dw 7x7 + bias + LayerNorm, pwconv1 + GELU with the
  * 4c-wide hidden tile kept in registers, GRN (the workgroups of an image meet at a per-image barrier for sum_hw h^2), pwconv2 + residual.
  * x, y: N x H x W x c NHWC views (y may not alias x: neighbouring tiles read x's halo), dw_w49c [49][c] fp32 (tap-major), packed: the blob of
- * mgdt_cnx_mlp_pack.  ws (mgdt_cnx_block_workspace_bytes, 16-byte aligned): its first 4096 bytes are arrival counters that MUST BE ZERO at the
- * first call and belong to this function from then on (they advance by a multiple of the tile count per call, so hipGraph replays need no
- * reset).  mgdt_cnx_block_supported: c in {32, 64, 96}, bf16, a tile decomposition with at most as many tiles per image as the chip has
+ * mgdt_cnx_mlp_pack.  ws (mgdt_cnx_block_workspace_bytes, 16-byte aligned): its first 4096 bytes are the per-image barrier words (arrival
+ * counter + generation) that MUST BE ZERO at the first call and belong to this function from then on (the counters are back at zero when a
+ * call ends, so hipGraph replays and calls with other shapes need no reset; at most 512 images per call).  mgdt_cnx_block_supported: c in {32, 64, 96}, bf16, a tile decomposition with at most as many tiles per image as the chip has
  * compute units (every workgroup of a launch is resident at once; larger batches run as several launches of whole images). */
 int mgdt_cnx_block_supported(int n, int h, int w, int c, int dtype);
 size_t mgdt_cnx_block_workspace_bytes(int n, int h, int w, int c);
@@ -222,9 +222,11 @@ int mgdt_scale_channels_fwd(const mgdt_view* x, const float* attn, const mgdt_vi
 /* spr_attn + scale_channels in one launch: every workgroup recomputes its image's attention (same order, same bits) and scales
  * a share of the pixels: y = x * softmax_groups(SPR(pooled)).  `pooled` as written by mgdt_spr_pool_fwd (nsplit = MGDT_SPR_SPLITS, or 0)
  * with tiles_x = tiles_y = 0: fp32 [n][nsplit][c][5]; or the per-tile sums of mgdt_csp_block_fwd: fp32 [n][nsplit][c], tiles_x x tiles_y
- * its tile grid. */
+ * its tile grid.  pool_a / pool_b (NULL or NHWC views of the same n, c with h = H / F, w = W / F, F integer): F x F average pools of y, bit-equal
+ * to mgdt_adaptive_avgpool_fwd(y) - the SimFusion_4in / SimFusion_3in inputs of the GD neck (nn/modules/block.py:289-329), written by the
+ * pass that has the map in hand instead of by pooling launches of their own. */
 int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tiles_x, int tiles_y, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
-                            const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s);
+                            const mgdt_view* x, const mgdt_view* y, const mgdt_view* pool_a, const mgdt_view* pool_b, int dtype, mgdt_stream s);
 
 /* ---- SPPF pooling: y1,y2,y3 = maxpool5(x), maxpool5(y1), maxpool5(y2) (nn/modules/block.py:138-153) ----- */
 int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const mgdt_view* y2, const mgdt_view* y3, int dtype,

@@ -12,9 +12,10 @@
 //
 // Why a barrier between workgroups is safe here: the grid never exceeds the number of workgroups the chip holds at once (host side:
 // images per launch = 256 / tiles per image, one workgroup per CU by LDS size), workgroups are dispatched in index order, and a waiting
-// workgroup waits only for workgroups with the same image index.  The counter is monotone (target = next multiple of `tiles`), so the
-// kernel can be replayed from a hipGraph without resetting anything.  What crosses workgroups (the partial sums, the counter) moves
-// through agent-scope atomics only - no cache-wide release / acquire fence (see the exchange below).
+// workgroup waits only for workgroups with the same image index.  The barrier is an arrival counter + a generation word per image and is
+// back in its rest state when the kernel ends, so it can be replayed from a hipGraph (and called with other shapes) without resetting
+// anything.  What crosses workgroups (the partial sums, the counter, the generation) moves through agent-scope atomics only - no
+// cache-wide release / acquire fence (see the exchange below).
 //
 // LDS (C = 96, 10x20 tile: 143 KiB, one workgroup of 16 waves per CU):
 //   U   80 KiB  halo tile (A)  ->  LayerNorm partial sums (A)  ->  pwconv1 panel (B)  ->  pwconv2 panel (C)
@@ -33,7 +34,7 @@ struct CnxArgs {
   const char* packed;                                   // W1 | W2 | b1 | b2 (mgdt_cnx_mlp_pack)
   const float* gamma; const float* beta;
   float* part;                                          // [N][tiles][4C] per-tile sums of h^2
-  unsigned* sync;                                       // [N] arrival counters (monotone)
+  unsigned* sync;                                       // [N][2] arrival counter (0 at rest), generation
   int N, H, W, C, TH, TW, RH, RW, SEGS, tiles_x, tiles, n0;
   FastDiv fd_rw, fd_tw;
   GeluCoef gelu;
@@ -81,6 +82,10 @@ __global__ __launch_bounds__(CNX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   unsigned long long TT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (dbg) TT[0] = wall_clock64();
 
+  // this image's barrier generation, read long before this workgroup arrives at the barrier (it cannot change until every workgroup of the
+  // image - this one included - has arrived)
+  unsigned gen0 = 0;
+  if (tid == 0) gen0 = __hip_atomic_load(a.sync + 2 * n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
 
@@ -297,9 +302,16 @@ __global__ __launch_bounds__(CNX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   }
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(a.sync + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = (old / (unsigned)a.tiles + 1u) * (unsigned)a.tiles;
-    while ((int)(__hip_atomic_load(a.sync + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
+    // arrival counter + generation: the last of the image's `tiles` workgroups resets the counter and opens the next generation; the others
+    // wait for the generation they read BEFORE arriving to change.  The pair is back in its rest state (counter 0) when the kernel ends,
+    // whatever the tile count was, so one workspace serves every shape and hipGraph replays need no reset.
+    const unsigned old = __hip_atomic_fetch_add(a.sync + 2 * n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)a.tiles - 1u) {
+      __hip_atomic_store(a.sync + 2 * n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.sync + 2 * n + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(a.sync + 2 * n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) __builtin_amdgcn_s_sleep(8);
+    }
   }
   __syncthreads();
   if (dbg) TT[5] = wall_clock64();
@@ -394,7 +406,7 @@ extern "C" int mgdt_cnx_block_supported(int n, int h, int w, int c, int dtype) {
   return cdiv(h, th) * cdiv(w, tw) <= 256;
 }
 
-/* workspace: [1024 arrival counters, uint32: MUST BE ZERO at first use and never written by anyone else] [n * tiles * 4c floats] */
+/* workspace: [512 x {arrival counter, generation}, uint32: MUST BE ZERO at first use and never written by anyone else] [n * tiles * 4c floats] */
 extern "C" size_t mgdt_cnx_block_workspace_bytes(int n, int h, int w, int c) {
   int th, tw;
   if (!cnx_pick_tile(h, w, c, &th, &tw)) return 0;
@@ -433,7 +445,7 @@ extern "C" int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, cons
   const int kc1 = cnx_kc1(x->c, dtype);
   if (!kc1 || !mgdt_cnx_block_supported(x->n, x->h, x->w, x->c, dtype)) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: n=%d %dx%d c=%d dtype=%d not covered", x->n, x->h, x->w, x->c, dtype);
   if (y->n != x->n || y->h != x->h || y->w != x->w || y->c != x->c) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: x and y must have one shape");
-  if (x->n > 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: at most 1024 images per call");
+  if (x->n > 512) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: at most 512 images per call");
   if (ws_bytes < mgdt_cnx_block_workspace_bytes(x->n, x->h, x->w, x->c) || (uintptr_t)ws % 16) MGDT_FAIL(MGDT_WORKSPACE, "cnx_block: workspace too small / unaligned");
   CnxArgs a;
   memset(&a, 0, sizeof(a));

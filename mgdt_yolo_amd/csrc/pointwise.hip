@@ -299,11 +299,15 @@ extern "C" int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const 
 // attention MLP + channel scaling in one launch: grid (K, N); every workgroup of image n recomputes the (tiny) SPR MLP of that image
 // from the pooled partial sums - identical arithmetic in identical order, so all K copies agree bit for bit - keeps the C softmax
 // weights in LDS and scales its 1/K share of the pixels.  Saves a dependent launch per MSPA block.
+// optional extra outputs of the scaling pass: F x F average pools of the SCALED map (adaptive_avg_pool2d with H % F == W % F == 0), written
+// where the GD neck's SimFusion modules would otherwise launch their own pooling kernels (nn/modules/block.py:289-329)
+struct SprPool { void* y; long sn, sh, sw; int F; };
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
                                                              const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh,
-                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit, int tiles_x, int tiles_y) {
+                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit, int tiles_x, int tiles_y, SprPool pa, SprPool pb) {
   extern __shared__ float sm[];
   const int n = blockIdx.y, cw = C / G, hid = cw / 4;
   float* pooled = sm;               // [C][5] means
@@ -409,10 +413,37 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
     for (int k = 0; k < V; ++k) v[k] *= att[qv + k];
     stv<T, V>(y + yo, v);
   }
+  // pooled copies: exactly what mgdt_adaptive_avgpool_fwd computes from the stored map - every scaled value rounded to T first, summed row by
+  // row in fp32, times 1 / F^2 - from x again (this workgroup's share of the image was just streamed through L2)
+  const SprPool pools[2] = {pa, pb};
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    const SprPool P = pools[pi];
+    if (P.F == 0) continue;
+    const int F = P.F, Ho = H / F, Wo = W / F, HWo = Ho * Wo;
+    const int q0 = (int)((long)blockIdx.x * HWo / gridDim.x), q1 = (int)((long)(blockIdx.x + 1) * HWo / gridDim.x);
+    const float inv = 1.f / (float)(F * F);
+    for (int j = threadIdx.x; j < (q1 - q0) * Q; j += 256) {
+      const int pl = j / Q, q = j - pl * Q, po = q0 + pl, oy = po / Wo, ox = po - oy * Wo;
+      float a[V], acc[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) { a[k] = att[q * V + k]; acc[k] = 0.f; }
+      for (int yy = 0; yy < F; ++yy)
+        for (int xx = 0; xx < F; ++xx) {
+          float v[V];
+          ldv<T, V>(x + n * xsn + (long)(oy * F + yy) * xsh + (long)(ox * F + xx) * xsw + q * V, v);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[k] += (float)(T)(v[k] * a[k]);
+        }
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] *= inv;
+      stv<T, V>((T*)P.y + n * P.sn + oy * P.sh + ox * P.sw + q * V, acc);
+    }
+  }
 }
 
 extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tiles_x, int tiles_y, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
-                                       const mgdt_view* x, const mgdt_view* y, int dtype, mgdt_stream s) {
+                                       const mgdt_view* x, const mgdt_view* y, const mgdt_view* pool_a, const mgdt_view* pool_b, int dtype, mgdt_stream s) {
   if (nsplit <= 0) nsplit = SPR_SPLITS;
   if (tiles_x > 0 && (tiles_y <= 0 || nsplit % (tiles_x * tiles_y) || tiles_x % 2 || tiles_y % 2 || x->h % 2 || x->w % 2))
     MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: per-tile sums need an even tile grid over an even map (nsplit=%d tiles %dx%d)", nsplit, tiles_y, tiles_x);
@@ -423,7 +454,18 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tile
     MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: views must be matching NHWC, c%%4==0");
   const int cw = c / groups, hid = cw / 4;
   const size_t lds = (size_t)(c * 5 + groups * hid + 2 * c) * sizeof(float);
-  MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8), {
+  SprPool pl[2] = {{nullptr, 0, 0, 0, 0}, {nullptr, 0, 0, 0, 0}};
+  bool pool8 = true;
+  const mgdt_view* pv[2] = {pool_a, pool_b};
+  for (int i = 0; i < 2; ++i) {
+    const mgdt_view* p = pv[i];
+    if (!p || !p->p) continue;
+    if (!view_ok(p) || !vec4_ok(p, dtype) || p->n != x->n || p->c != c || p->h < 1 || x->h % p->h || x->w % p->w || x->h / p->h != x->w / p->w)
+      MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: a pooled output must be an NHWC view of the same n, c whose size divides the map by one factor");
+    pl[i].y = p->p; pl[i].sn = p->sn; pl[i].sh = p->sh; pl[i].sw = p->sw; pl[i].F = x->h / p->h;
+    pool8 = pool8 && vecN_ok(p, dtype, 8);
+  }
+  MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8) && pool8, {
     const long vecs = (long)x->h * x->w * (c / V);
     static const long per_wg = getenv("MGDT_SPR_VECS") ? atol(getenv("MGDT_SPR_VECS")) : 2048;   // experiment knob: vectors per workgroup
     // every workgroup repeats the attention prologue (the reduction of the per-tile sums dominates it): ~12 workgroups per image measured best on all
@@ -431,7 +473,7 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tile
     const int K = (int)std::max<long>(1, std::min<long>(12, vecs / per_wg));
     spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
                                                                               x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
-                                                                              make_fastdiv((uint32_t)x->w), nsplit, tiles_x, tiles_y);
+                                                                              make_fastdiv((uint32_t)x->w), nsplit, tiles_x, tiles_y, pl[0], pl[1]);
   });
   MGDT_CHECK_LAUNCH("spr_attn_scale_fwd");
   return MGDT_OK;

@@ -136,9 +136,13 @@ class MSPA_C2f(HipModule):
         self.attention = SPRModule(self.outwidth)
         self.softmax = nn.Softmax(dim=1)
 
-    def forward(self, x):
+    def forward(self, x, deliver=None):
+        """`deliver` (set by the model's neck plan, eval only): {'out': view to write the block output into (a slot of a consumer's concat
+        buffer) or None, 'pools': views receiving adaptive_avg_pool2d(output)} - both served by the attention-scaling launch."""
         if self.stride != 1:
             raise RuntimeError('MSPA_C2f: only stride=1 is wired by parse_model and built here')
+        d_out = deliver.get('out') if deliver else None
+        d_pools = deliver.get('pools', ()) if deliver else ()
         b, _, h, w = x.shape
         wd, s, n = self.inwidth, self.nums, self.btnk_nums
         train = self.training and hasattr(self.convs[0], 'bn')
@@ -151,7 +155,7 @@ class MSPA_C2f(HipModule):
             mids = [pk for m in self.bottleneck for pk in (m.cv1.packed(dt, False), m.cv2.packed(dt, False))]
             out, pool, slots, tiles = ops.csp_block(ops.CSP_MSPA, x, self._packed_chain(dt).blob, None, mids, self.bottleneck[0].add,
                                                     self.convs[3].packed(dt, False), wd, act_code(self.convs[0].act), self.convs[3].conv.out_channels, True)
-            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, part=pool, nsplit=slots, tiles=tiles)
+            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, out=d_out, part=pool, nsplit=slots, tiles=tiles, pools=d_pools)
         cat = ops.new_act(b, (s - 1 + n) * wd, h, w, dt, x.device)
         # sp_i = convs[i](sp_{i-1} + spx[i]) written straight into its concat slot (block.py:250-259)
         if not train and s == 4 and ops.pw_chain_supported(wd, cat.dtype) and x.dtype == cat.dtype and self._chain_ok():
@@ -171,7 +175,7 @@ class MSPA_C2f(HipModule):
             attn, part = ops.spr_attention_train(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)
             self._save_ctx((out, attn, part, x.shape))
         else:
-            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s)   # pool, then MLP + scaling in one launch
+            return ops.spr_attention_scale(out, at.fc1.weight, at.fc1.bias, at.fc2.weight, at.fc2.bias, s, out=d_out, pools=d_pools)   # pool, then MLP + scaling in one launch
         return ops.scale_channels(out, attn)
 
     def _chain_ok(self):
@@ -279,16 +283,28 @@ class Upsample(nn.Module):
 class SimFusion_4in(nn.Module):
     """FAM (reference block.py:289-307): resample 4 levels to the 3rd one's size and concatenate."""
 
-    def forward(self, x):
+    def forward(self, x, pre=None):
+        """`pre` (the model's neck plan, eval only): {'out': the concat buffer, 'done': slots their producers already wrote} - the MSPA blocks'
+        attention-scaling launches leave their pooled copies / their own output in place, so those branches launch nothing here."""
         x_l, x_m, x_s, x_n = x
         b, c, h, w = x_s.shape
         cs = [x_l.shape[1], x_m.shape[1], c, x_n.shape[1]]
         self._shapes = [t.shape for t in x]
-        out = ops.new_act(b, sum(cs), h, w, x_s.dtype, x_s.device)
+        out, done = None, ()
+        if pre is not None and pre.get('out') is not None and tuple(pre['out'].shape) == (b, sum(cs), h, w) and pre['out'].dtype == x_s.dtype:
+            out, done = pre['out'], pre['done']
+        if out is None:
+            out = ops.new_act(b, sum(cs), h, w, x_s.dtype, x_s.device)
         o = 0
-        ops.adaptive_avgpool(x_l, out[:, o:o + cs[0]]); o += cs[0]
-        ops.adaptive_avgpool(x_m, out[:, o:o + cs[1]]); o += cs[1]
-        ops.copy(x_s, out[:, o:o + cs[2]]); o += cs[2]
+        if 0 not in done:
+            ops.adaptive_avgpool(x_l, out[:, o:o + cs[0]])
+        o += cs[0]
+        if 1 not in done:
+            ops.adaptive_avgpool(x_m, out[:, o:o + cs[1]])
+        o += cs[1]
+        if not (2 in done and x_s.data_ptr() == out[:, o:o + cs[2]].data_ptr()):
+            ops.copy(x_s, out[:, o:o + cs[2]])
+        o += cs[2]
         ops.bilinear(x_n, out[:, o:o + cs[3]])
         return out
 
@@ -310,20 +326,28 @@ class SimFusion_3in(HipModule):
         self.cv3 = Conv(in_channel_list[2], out_channels, act=nn.ReLU()) if in_channel_list[2] != out_channels else nn.Identity()
         self.cv_fuse = Conv(out_channels * 3, out_channels, act=nn.ReLU())
 
-    def forward(self, x):
+    def forward(self, x, pre=None):
+        """`pre` (the model's neck plan, eval only): {'out': the concat buffer, 'done': slots already in place, 'pooled0': avg-pooled x[0]}."""
         b, _, h, w = x[1].shape
         oc = self.cv_fuse.conv.out_channels
         dt, dev = x[1].dtype, x[1].device
         self._shapes = [t.shape for t in x]
-        cat = ops.new_act(b, 3 * oc, h, w, dt, dev)
+        cat, done, pooled0 = None, (), None
+        if pre is not None and pre.get('out') is not None and tuple(pre['out'].shape) == (b, 3 * oc, h, w) and pre['out'].dtype == dt:
+            cat, done, pooled0 = pre['out'], pre['done'], pre.get('pooled0')
+        if cat is None:
+            cat = ops.new_act(b, 3 * oc, h, w, dt, dev)
         # branch 0: adaptive avg-pool then (optional) 1x1 ReLU conv
         if isinstance(self.cv1, nn.Identity):
-            ops.adaptive_avgpool(x[0], cat[:, :oc])
+            if 0 not in done:
+                ops.adaptive_avgpool(x[0], cat[:, :oc])
         else:
-            (self.cv1.train_fwd if (self.training and hasattr(self.cv1, 'bn')) else self.cv1.run)(
-                ops.adaptive_avgpool(x[0], ops.new_act(b, x[0].shape[1], h, w, dt, dev)), out=cat[:, :oc])
+            if pooled0 is None or tuple(pooled0.shape) != (b, x[0].shape[1], h, w):
+                pooled0 = ops.adaptive_avgpool(x[0], ops.new_act(b, x[0].shape[1], h, w, dt, dev))
+            (self.cv1.train_fwd if (self.training and hasattr(self.cv1, 'bn')) else self.cv1.run)(pooled0, out=cat[:, :oc])
         if isinstance(self.cv2, nn.Identity):
-            ops.copy(x[1], cat[:, oc:2 * oc])
+            if not (1 in done and x[1].data_ptr() == cat[:, oc:2 * oc].data_ptr()):
+                ops.copy(x[1], cat[:, oc:2 * oc])
         else:
             (self.cv2.train_fwd if (self.training and hasattr(self.cv2, 'bn')) else self.cv2.run)(x[1], out=cat[:, oc:2 * oc])
         if isinstance(self.cv3, nn.Identity):

@@ -89,12 +89,94 @@ class BaseModel(nn.Module):
             x = ops.stem2(x, pk0, m1.packed(torch.bfloat16, direct=False))
             y = [None, x if 1 in self.save else None]
             layers = list(self.model)[2:]
+        plan = self._neck_plan(x) if not self.training else None
+        bufs = {}                                           # consumer layer -> {'out': concat buffer, 'done': slots, 'pooled0': ...}
         for m in layers:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
+            if plan is not None and m.i in plan['producers']:
+                x = m(x, deliver=self._neck_deliveries(plan, m, x, bufs))
+            elif plan is not None and m.i in plan['consumers']:
+                x = m(x, pre=bufs.get(m.i))
+            else:
+                x = m(x)
             y.append(x if m.i in self.save else None)
         return x
+
+    # -- GD-neck data movement folded into the producers ------------------------------------
+    def _neck_plan(self, x):
+        """Which MSPA_C2f layers can hand their output to a SimFusion_4in / SimFusion_3in consumer without a launch of its own
+        (nn/modules/block.py:289-329): an avg-pooled input becomes a pooled copy written by the block's attention-scaling launch, an identity
+        input becomes that launch writing straight into the consumer's concat slot.  Static per model: {'producers': {layer: [(kind, consumer,
+        slot)]}, 'consumers': {layers}}.  bf16 inference only, and nobody watching the layers involved (forward hooks)."""
+        if not ops.FUSED_NECK or getattr(self, 'compute_dtype', None) != torch.bfloat16 or not hasattr(self, '_reductions'):
+            return None
+        plan = self.__dict__.get('_neck_plan_cache')
+        if plan is None:
+            prod, cons = {}, set()
+            absf = lambda m: [m.i + f if f < 0 else f for f in ([m.f] if isinstance(m.f, int) else m.f)]
+            for m in self.model:
+                if isinstance(m, SimFusion_4in):
+                    src = absf(m)
+                    kinds = ('pool', 'pool', 'main')
+                elif isinstance(m, SimFusion_3in):
+                    src = absf(m)
+                    kinds = ('pool', 'main' if isinstance(m.cv2, nn.Identity) else None)
+                else:
+                    continue
+                for slot, kind in enumerate(kinds):
+                    j = src[slot]
+                    if kind is None or not isinstance(self.model[j], MSPA_C2f):
+                        continue
+                    if kind == 'main' and any(k == 'main' for k, _, _ in prod.get(j, [])):
+                        continue                             # a block output can live in one concat buffer only
+                    prod.setdefault(j, []).append((kind, m.i, slot))
+                    cons.add(m.i)
+            plan = self.__dict__['_neck_plan_cache'] = {'producers': prod, 'consumers': cons} if prod else False
+        if not plan:
+            return None
+        if any(self.model[i]._forward_hooks for i in list(plan['producers']) + list(plan['consumers'])):
+            return None
+        return plan
+
+    def _neck_deliveries(self, plan, m, x, bufs):
+        """Views the MSPA block `m` (input x: its output has the same shape) writes for its SimFusion consumers; allocates their buffers."""
+        b, c, h, w = x.shape
+        out, pools = None, []
+        red = self._reductions
+        absf = lambda mm: [mm.i + f if f < 0 else f for f in ([mm.f] if isinstance(mm.f, int) else mm.f)]
+        for kind, ci, slot in plan['producers'][m.i]:
+            cm = self.model[ci]
+            src = absf(cm)
+            tgt = src[2] if isinstance(cm, SimFusion_4in) else src[1]         # the input whose size the module resamples to (block.py:294,316)
+            if red[tgt] % red[m.i]:
+                continue
+            F = int(red[tgt] // red[m.i])
+            if F < 1 or h % F or w % F or (kind == 'main' and F != 1) or (kind == 'pool' and F == 1):
+                continue
+            th, tw = h // F, w // F
+            if isinstance(cm, SimFusion_4in):
+                cs = [self.model[j].c2 for j in src]
+                total, off = sum(cs), sum(cs[:slot])
+            else:
+                oc = cm.cv_fuse.conv.out_channels
+                total, off = 3 * oc, slot * oc
+            st = bufs.setdefault(ci, {'out': None, 'done': set()})
+            if st['out'] is None:
+                st['out'] = ops.new_act(b, total, th, tw, x.dtype, x.device)
+            if tuple(st['out'].shape) != (b, total, th, tw):
+                continue
+            if isinstance(cm, SimFusion_3in) and slot == 0 and not isinstance(cm.cv1, nn.Identity):
+                st['pooled0'] = ops.new_act(b, c, th, tw, x.dtype, x.device)      # the pooled map feeds cv1, not the concat buffer
+                pools.append(st['pooled0'])
+                continue
+            view = st['out'][:, off:off + c]
+            if kind == 'pool':
+                pools.append(view)
+            else:
+                out = view
+            st['done'].add(slot)
+        return {'out': out, 'pools': pools[:2]} if (out is not None or pools) else None
 
     def _stem_fusable(self, x):
         """layers 0, 1 = Conv(3, 16, 3, 2) -> Conv(16, 32, 3, 2) with BN + SiLU, bf16 compute, layer 0's output used by layer 1 only, and nobody
@@ -282,6 +364,7 @@ class DetectionModel(BaseModel):
         if nc and nc != self.yaml['nc']:
             self.yaml['nc'] = nc
         self.model, self.save, reductions = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self._reductions = list(reductions)          # total down-sampling of every layer's output (the neck plan derives pooling factors from it)
         self.names = {i: f'{i}' for i in range(self.yaml['nc'])}
         self.inplace = self.yaml.get('inplace', True)
         self.compute_dtype = torch.float32
@@ -379,6 +462,7 @@ def parse_model(d, ch, verbose=True):
         t = f'{m.__module__}.{m.__name__}'
         m.np = sum(x.numel() for x in m_.parameters())
         m_.i, m_.f, m_.type = i, f, t
+        m_.c2 = None if m in (Detect, TOODHead) else c2          # output channels (the neck plan sizes the SimFusion buffers from them)
         if verbose:
             print(f'{i:>3}{str(f):>20}{n_:>3}{m.np:10.0f}  {t:<45}{str(args):<30}')
         save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)

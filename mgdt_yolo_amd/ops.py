@@ -304,18 +304,27 @@ def spr_attention(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, softmax=True):
     return attn
 
 
-def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=None, nsplit=0, tiles=(0, 0)):
+def spr_attention_scale(x, fc1_w, fc1_b, fc2_w, fc2_b, groups, out=None, part=None, nsplit=0, tiles=(0, 0), pools=()):
     """out = x * softmax_over_groups(SPR(x_group)): pooling pass (skipped when the producing kernel already left its per-tile sums in
-    `part`, fp32 [b][nsplit][c] over a tiles[0] x tiles[1] (x, y) tile grid), then attention MLP + scaling in one launch."""
+    `part`, fp32 [b][nsplit][c] over a tiles[0] x tiles[1] (x, y) tile grid), then attention MLP + scaling in one launch.  `pools`: up to two
+    NHWC views (b, c, h / F, w / F) that receive adaptive_avg_pool2d(out) in the same launch."""
     b, c, h, w = x.shape
     if part is None:
         part = torch.empty(b * L.SPR_SPLITS * c * 5, dtype=torch.float32, device=x.device)
         _launch('spr_pool_fwd', 'mgdt_spr_pool_fwd', vp(x), ptr(part), dtype_code(x.dtype), stream())
         nsplit, tiles = L.SPR_SPLITS, (0, 0)
     out = like(x) if out is None else out
+    pools = list(pools)
+    if len(pools) > 2:
+        raise RuntimeError('spr_attention_scale: at most two pooled outputs')
+    _same(x, out, *pools)
+    pa, pb = (pools + [None, None])[:2]
     _launch('spr_attn_scale_fwd', 'mgdt_spr_attn_scale_fwd', ptr(part), int(nsplit), int(tiles[0]), int(tiles[1]), ptr(fc1_w), ptr(fc1_b), ptr(fc2_w), ptr(fc2_b), groups, vp(x), vp(out),
-            dtype_code(x.dtype), stream())
+            vp(pa), vp(pb), dtype_code(x.dtype), stream())
     return out
+
+
+FUSED_NECK = True     # tests flip this: SimFusion inputs delivered by their producers (pooled copies / direct concat-slot writes) vs separate launches
 
 
 # ------------------------------------------------------------------ layers 0 + 1 in one launch
@@ -501,7 +510,7 @@ def cnx_mlp(t, res, pk, gamma, beta, out=None):
 
 
 FUSED_CNX_BLOCK = True  # tests flip this to compare against dwconv7_ln + the two-pass MLP
-_CNX_WS = {}            # (device, bytes) -> zero-initialised workspace of mgdt_cnx_block_fwd (its arrival counters live across calls)
+_CNX_WS = {}            # (device, shape) -> zero-initialised workspace of mgdt_cnx_block_fwd (its barrier words live across calls)
 
 
 def cnx_block_supported(x, dtype):
@@ -516,7 +525,7 @@ def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None):
     if out.data_ptr() == x.data_ptr():
         raise RuntimeError('cnx_block: the output may not alias the input (tiles read their neighbours\' halo)')
     nbytes = L.lib().mgdt_cnx_block_workspace_bytes(b, h, w, c)
-    key = (x.device, nbytes)
+    key = (x.device, b, c, h, w)
     ws = _CNX_WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():

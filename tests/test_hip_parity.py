@@ -131,6 +131,36 @@ def test_convnext_block_single_launch_matches_the_launch_chain(b, dim, hw):
     assert e_chain < 2e-2 * scale and e32 < 3e-2 * scale
 
 
+def test_convnext_block_barrier_words_survive_a_change_of_shape():
+    """The per-image barrier of mgdt_cnx_block_fwd (arrival counter + generation in the workspace) must be at rest after every call whatever
+    the tile count was: one workspace shared by a 1-tile-per-image shape (called an odd number of times) and a 2-tile-per-image shape.  (The
+    first form of the barrier - a monotone counter with target = next multiple of the tile count - hung exactly here: round-3 log.)"""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import ConvNeXtV2_Block
+    m = seed_state_dict_(ConvNeXtV2_Block(96), 3).eval().to(DEV)
+    mk = lambda b, h, w: torch.randn(b, 96, h, w, generator=torch.Generator().manual_seed(b + h)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa, xb = mk(4, 10, 10), mk(2, 20, 20)
+    shared = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    keys = [(xa.device, 4, 96, 10, 10), (xb.device, 2, 96, 20, 20)]
+    saved = {k: ops._CNX_WS.get(k) for k in keys}
+    try:
+        for k in keys:
+            ops._CNX_WS[k] = shared
+        with torch.no_grad():
+            ya = [m(xa) for _ in range(3)]
+            yb = [m(xb) for _ in range(3)]
+            ya2 = m(xa)
+        torch.cuda.synchronize()
+        assert torch.equal(ya[0], ya[2]) and torch.equal(ya[0], ya2) and torch.equal(yb[0], yb[2])
+        assert int(shared[:4096].view(torch.int32)[0::2].abs().sum()) == 0, 'arrival counters must be back at zero'
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                ops._CNX_WS.pop(k, None)
+            else:
+                ops._CNX_WS[k] = v
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('b,c,hw', [(32, 96, (40, 40)), (3, 96, (23, 17)), (2, 64, (13, 9)), (1, 32, (7, 21)), (2, 160, (12, 10))],
                          ids=['bench-tile10', 'odd-96', 'c64', 'c32', 'c160-tiled'])
@@ -1149,6 +1179,40 @@ def test_validator_surface_matches_reference_call_form(golden):
         det, lab = GI.val_match_inputs(seed, nd, nl)
         c = v._process_batch(torch.from_numpy(det).to(DEV), torch.from_numpy(lab).to(DEV))
         assert c.dtype == torch.bool and c.device.type == 'cuda' and np.array_equal(c.cpu().numpy(), g[f'c{seed}']), seed
+
+
+@pytest.mark.parametrize('shape', [(2, 640, 640), (3, 320, 256), (1, 224, 352)])
+def test_neck_inputs_delivered_by_their_producers(shape):
+    """GD-neck data movement folded into the producers (ops.FUSED_NECK): the MSPA blocks' attention-scaling launches write the avg-pooled
+    copies SimFusion_4in / SimFusion_3in need and, for identity branches, their own output straight into the consumer's concat slot - five
+    launches (3 avg-pools, 2 copies) fewer per forward.  The pooled values reproduce mgdt_adaptive_avgpool_fwd bit for bit, so the whole
+    model output must be IDENTICAL to the separate-launch form; shapes whose maps do not divide by the pooling factors fall back by
+    themselves (224 / 4 / 4 is not an integer number of 2x2 bins at the 4x factor's level -> those inputs keep their own launches)."""
+    from mgdt_yolo_amd import ops
+    m = build_model('mspa_c2f_gd_yolov8', torch.bfloat16)
+    x = seeded_images(shape[0], shape[1], shape[2], seed=9).to(DEV).to(torch.bfloat16)
+    launches = {}
+    with torch.no_grad():
+        m(x)                                                 # weight panels are packed on first use: keep those launches out of the count
+        for flag in (True, False):
+            ops.FUSED_NECK = flag
+            try:
+                names = []
+                orig = ops._launch
+                ops._launch = lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1]
+                try:
+                    y, feats = m(x)
+                finally:
+                    ops._launch = orig
+                launches[flag] = (y.clone(), [f.clone() for f in feats], names)
+            finally:
+                ops.FUSED_NECK = True
+    (y1, f1, n1), (y0, f0, n0) = launches[True], launches[False]
+    assert torch.equal(y1, y0) and all(torch.equal(a, b) for a, b in zip(f1, f0))
+    saved = len(n0) - len(n1)
+    print(shape, 'launches', len(n0), '->', len(n1))
+    if shape[1] % 32 == 0 and shape[2] % 32 == 0:
+        assert saved == 5 and n1.count('adaptive_avgpool_fwd') == 0 and n1.count('copy_fwd') == 0, (saved, n1)
 
 
 def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
