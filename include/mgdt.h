@@ -175,6 +175,14 @@ int mgdt_conv1x1_inject_supported(int cin, int cout, int h, int w, int hg, int w
 int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
                             const mgdt_view* y, int dtype, mgdt_stream s);
 
+/* ---- injection + the NEXT layer's 1x1 Conv+BN+act in one launch (models/v8/mspa_c2f_gd_yolov8.yaml head rows 4-5: the injection's 256-channel
+ * output has one consumer, C2f.cv1, nn/modules/block.py:199-201): y2 = act2(conv1x1(injection(x, ga, gf)) + bias2), the 256-channel map never
+ * leaves the chip.  packed_w2 / bias2: mgdt_conv_pack(256, cout2, 1, bf16) of the second conv with its INPUT channels permuted to the first
+ * conv's accumulator order: packed input channel (j*4 + g)*8 + e <- channel (2*j + e/4)*16 + 4*g + e%4 (j < 8, g < 4, e < 8). */
+int mgdt_conv1x1_inject_conv_supported(int cin, int cmid, int cout2, int h, int w, int hg, int wg, int dtype);
+int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+                                 const void* packed_w2, const float* bias2, int act2, const mgdt_view* y2, int dtype, mgdt_stream s);
+
 /* ---- TOODHead (nn/modules/head.py:466-572; parity unpinned: mmcv's ModulatedDeformConv2d is not shipped with the reference) --------
  * GroupNorm + activation (Conv_GN head.py:67-81, DyDCNv2's norm block.py:427-431): y = act(group_norm(x, groups, gamma, beta, eps)). */
 size_t mgdt_groupnorm_workspace_bytes(int n, int c);

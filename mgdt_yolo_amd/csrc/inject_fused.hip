@@ -130,6 +130,130 @@ __global__ __launch_bounds__(INJ_THREADS) void conv1x1_inject_kernel(const InjAr
   }   // patch loop
 }
 
+// ---- the same with the NEXT layer's 1x1 convolution behind it ------------------------------------------------------------------------
+// In the GD neck the injection's 256-channel output has ONE consumer: C2f.cv1, a 1x1 Conv + BN + SiLU down to 64 channels
+// (models/v8/mspa_c2f_gd_yolov8.yaml head rows 4-5; nn/modules/block.py:199-201).  Written out and read back, that map is 105 MB each way at
+// B = 32, 80x80 - more than everything else the two launches move.  Here the injected values go from the first GEMM's accumulators through
+// the bilinear tail straight into the second GEMM's B operand (the accumulator layout of one MFMA is the B layout of the next once the
+// second panel's K order is permuted to match - the trick of mgdt_cnx_mlp_fwd), rounded to bf16 exactly where the stored map would be:
+// x (64 ch) + the two global maps in, 64 channels out.  Workgroup = TH waves = a TH x 16 patch; both panels + both source patches in LDS.
+struct InjConvArgs {
+  InjArgs a;
+  const char* w2; const float* bias2;      // 1x1 panel of the second conv with its K (= Cout of the injection) in ACCUMULATOR order, BN folded
+  char* y2; int y2sn, y2sh, y2sw; uint32_t y2_bytes;
+  int C2, act2;
+};
+
+template <int KC, int NB, int NB2, int TH>
+__global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjConvArgs A) {
+  typedef bf16 T;
+  typedef bf16x8 frag;
+  const InjArgs& a = A.a;
+  constexpr int SZ = 2, THREADS = 64 * TH;
+  constexpr int CS = NB * 16 + INJ_CPAD;
+  constexpr int KC2 = NB / 2;                              // K chunks of the second conv: two 16-row blocks of the first conv's output each
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;                                         // [KC][NB][64][16 B]
+  char* w2l = smem + (size_t)KC * NB * 1024;               // [KC2][NB2][64][16 B]
+  T* sg = (T*)(w2l + (size_t)KC2 * NB2 * 1024);
+  T* sf = sg + (size_t)a.PH * a.PW * CS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < KC * NB * 64; i += THREADS) ((uint4*)wl)[i] = ((const uint4*)a.wpk)[i];
+  for (int i = tid; i < KC2 * NB2 * 64; i += THREADS) ((uint4*)w2l)[i] = ((const uint4*)A.w2)[i];
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)A.y2, 0, A.y2_bytes, 0x00020000);
+  const char* const wlane = wl + lane * 16;
+  const char* const w2lane = w2l + lane * 16;
+  const int npatch = a.N * a.tiles_x * a.tiles_y;
+#pragma unroll 1
+  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+    int b = patch;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y, n = b / a.tiles_y;
+    const int oy = ty * TH + wave, ox = tx * INJ_TW + r;
+    const bool pv = oy < a.H && ox < a.W;
+    const int xo = pv ? n * a.xsn + oy * a.xsh + ox * a.xsw : MGDT_OOB;
+    frag P[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int cb = (kc * 4 + g) * 16;
+      P[kc] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, (cb < a.Cin * SZ) ? (uint32_t)(xo + cb) : (uint32_t)MGDT_OOB, 0, 0));
+    }
+    int py0, py1, px0, px1, t0, t1; float tl;
+    inj_lerp(ty * TH, a.Hg, a.H, py0, t1, tl);
+    inj_lerp(min(ty * TH + TH - 1, a.H - 1), a.Hg, a.H, t0, py1, tl);
+    inj_lerp(tx * INJ_TW, a.Wg, a.W, px0, t1, tl);
+    inj_lerp(min(tx * INJ_TW + INJ_TW - 1, a.W - 1), a.Wg, a.W, t0, px1, tl);
+    const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;
+    __syncthreads();                                       // the previous patch's tail is done with the LDS maps
+    {
+      constexpr int VPP = NB * 16 / 8;
+      const int nvec = ph * pw * VPP;
+      for (int i = tid; i < nvec; i += THREADS) {
+        const int v = i % VPP, p = i / VPP;
+        const int sy = p / pw, sx = p - sy * pw;
+        const long go = (long)n * a.gsn + (long)(py0 + sy) * a.gsh + (long)(px0 + sx) * a.gsw + v * 16;
+        const uint4 va = *(const uint4*)(a.ga + go), vf = *(const uint4*)(a.gf + go);
+        *(uint4*)((char*)sg + ((size_t)p * CS + v * 8) * SZ) = va;
+        *(uint4*)((char*)sf + ((size_t)p * CS + v * 8) * SZ) = vf;
+      }
+    }
+    __syncthreads();
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = *(const f32x4*)(a.bias + nb * 16 + 4 * g);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mma(*(const frag*)(wlane + (kc * NB + nb) * 1024), P[kc], acc[nb]);
+    int y0, y1, x0, x1; float wy1, wx1;
+    inj_lerp(min(oy, a.H - 1), a.Hg, a.H, y0, y1, wy1);
+    inj_lerp(min(ox, a.W - 1), a.Wg, a.W, x0, x1, wx1);
+    const int o00 = ((y0 - py0) * pw + (x0 - px0)) * CS + 4 * g, o01 = ((y0 - py0) * pw + (x1 - px0)) * CS + 4 * g;
+    const int o10 = ((y1 - py0) * pw + (x0 - px0)) * CS + 4 * g, o11 = ((y1 - py0) * pw + (x1 - px0)) * CS + 4 * g;
+    auto ld = [&](const T* base, int off) __attribute__((always_inline)) {
+      const bf16x4 v = *(const bf16x4*)(base + off);
+      return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    };
+    auto hs = [](f32x4 v) __attribute__((always_inline)) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fminf(fmaxf(fmaf(v[j], 1.f / 6.f, 0.5f), 0.f), 1.f);
+      return o;
+    };
+    f32x4 acc2[NB2];
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb) acc2[nb] = *(const f32x4*)(A.bias2 + nb * 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < KC2; ++j) {
+      frag B2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = (2 * j + h) * 16;
+        const f32x4 sig = (hs(ld(sg, o00 + c)) * (1.f - wx1) + hs(ld(sg, o01 + c)) * wx1) * (1.f - wy1) +
+                          (hs(ld(sg, o10 + c)) * (1.f - wx1) + hs(ld(sg, o11 + c)) * wx1) * wy1;
+        const f32x4 feat = (ld(sf, o00 + c) * (1.f - wx1) + ld(sf, o01 + c) * wx1) * (1.f - wy1) +
+                           (ld(sf, o10 + c) * (1.f - wx1) + ld(sf, o11 + c) * wx1) * wy1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B2[h * 4 + i] = (T)((float)(T)acc[2 * j + h][i] * sig[i] + feat[i]);   // both roundings of the unfused pair
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB2; ++nb) acc2[nb] = mma(*(const frag*)(w2lane + (j * NB2 + nb) * 1024), B2, acc2[nb]);
+    }
+    const int yo = pv ? n * A.y2sn + oy * A.y2sh + ox * A.y2sw : MGDT_OOB;
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb) {
+      const int c = nb * 16 + 4 * g;
+      f32x4 v = acc2[nb];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = A.act2 == MGDT_ACT_SILU ? v[i] * fast_sigmoid(v[i]) : act_apply(v[i], A.act2);
+      bstore4<T>(yrs, c < A.C2 ? (uint32_t)yo + (uint32_t)(c * SZ) : (uint32_t)MGDT_OOB, v);
+    }
+  }
+}
+
 static int inj_kc(int cin) { return (cin + 31) / 32; }   // K chunks of the packed 1x1 panel (mgdt_conv_pack layout)
 
 // largest source patch any workgroup needs (rows x cols)
@@ -200,4 +324,79 @@ extern "C" int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w,
   INJ_CASE(1, 8) INJ_CASE(2, 8) INJ_CASE(3, 8) INJ_CASE(4, 8) INJ_CASE(1, 16) INJ_CASE(2, 16) INJ_CASE(3, 16) INJ_CASE(4, 16)
 #undef INJ_CASE
   MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject: no kernel for kc=%d nb=%d", kc, nb);
+}
+
+// ---- injection + the following 1x1 conv ------------------------------------------------------------------------------------------------
+constexpr int INJ2_TH = 8;
+static void inj_patch_th(int H, int W, int Hg, int Wg, int TH, int* PH, int* PW) {
+  int ph = 1, pw = 1, a0, a1, b0, b1; float t;
+  for (int ty = 0; ty * TH < H; ++ty) {
+    inj_lerp(ty * TH, Hg, H, a0, a1, t);
+    inj_lerp(std::min(ty * TH + TH - 1, H - 1), Hg, H, b0, b1, t);
+    ph = std::max(ph, b1 - a0 + 1);
+  }
+  for (int tx = 0; tx * INJ_TW < W; ++tx) {
+    inj_lerp(tx * INJ_TW, Wg, W, a0, a1, t);
+    inj_lerp(std::min(tx * INJ_TW + INJ_TW - 1, W - 1), Wg, W, b0, b1, t);
+    pw = std::max(pw, b1 - a0 + 1);
+  }
+  *PH = ph; *PW = pw;
+}
+static size_t inj2_lds(int kc, int nb, int nb2, int PH, int PW) {
+  return (size_t)kc * nb * 1024 + (size_t)(nb / 2) * nb2 * 1024 + (size_t)2 * PH * PW * (nb * 16 + INJ_CPAD) * 2;
+}
+
+/* 1 when mgdt_conv1x1_inject_conv_fwd covers the shapes: bf16, cin <= 128 (% 8), injection width 256, second conv 256 -> cout2 <= 64 (% 16) */
+extern "C" int mgdt_conv1x1_inject_conv_supported(int cin, int cmid, int cout2, int h, int w, int hg, int wg, int dtype) {
+  if (dtype != MGDT_BF16 || cin % 8 || cin > 128 || cmid != 256 || cout2 % 16 || cout2 < 16 || cout2 > 64 || h < hg || w < wg || hg < 1 || wg < 1) return 0;
+  int PH, PW;
+  inj_patch_th(h, w, hg, wg, INJ2_TH, &PH, &PW);
+  return inj2_lds(inj_kc(cin), cmid / 16, cout2 / 16, PH, PW) <= 156 * 1024;
+}
+
+template <int KC, int NB2>
+static int inj2_launch(const InjConvArgs& A, size_t lds, hipStream_t st) {
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv1x1_inject_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH><<<std::min(A.a.N * A.a.tiles_x * A.a.tiles_y, 256), 64 * INJ2_TH, lds, st>>>(A);   // persistent: one per CU
+  MGDT_CHECK_LAUNCH("conv1x1_inject_conv_fwd");
+  return MGDT_OK;
+}
+
+extern "C" int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+                                            const void* packed_w2, const float* bias2, int act2, const mgdt_view* y2, int dtype, mgdt_stream s) {
+  if (!view_ok(x) || !view_ok(ga) || !view_ok(gf) || !view_ok(y2) || !packed_w || !bias || !packed_w2 || !bias2) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject_conv: null/empty argument");
+  if (!mgdt_conv1x1_inject_conv_supported(x->c, ga->c, y2->c, x->h, x->w, ga->h, ga->w, dtype))
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: shapes/dtype not covered (see mgdt_conv1x1_inject_conv_supported)");
+  const long sz = 2;
+  if (x->n != y2->n || x->h != y2->h || x->w != y2->w || ga->n != x->n || gf->n != x->n || gf->c != ga->c || ga->h != gf->h || ga->w != gf->w ||
+      ga->sn != gf->sn || ga->sh != gf->sh || ga->sw != gf->sw)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: x/y2 spatial sizes, ga/gf shapes and layouts must match");
+  auto ok = [&](const mgdt_view* v, int q) { return v->sc == 1 && v->sw % q == 0 && v->sh % q == 0 && v->sn % q == 0 && (uintptr_t)v->p % (q * sz) == 0; };
+  auto ext = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * sz; };
+  if (!ok(x, 8) || !ok(ga, 8) || !ok(gf, 8) || !ok(y2, 4) || ext(x) >= 0x7fffffffL || ext(y2) >= 0x7fffffffL)
+    MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: views must be aligned NHWC (sc == 1) and < 2 GiB");
+  InjConvArgs A;
+  memset(&A, 0, sizeof(A));
+  InjArgs& a = A.a;
+  a.x = (const char*)x->p; a.xsn = (int)(x->sn * sz); a.xsh = (int)(x->sh * sz); a.xsw = (int)(x->sw * sz); a.x_bytes = (uint32_t)ext(x);
+  a.ga = (const char*)ga->p; a.gf = (const char*)gf->p; a.gsn = (int)(ga->sn * sz); a.gsh = (int)(ga->sh * sz); a.gsw = (int)(ga->sw * sz);
+  a.wpk = (const char*)packed_w; a.bias = bias;
+  a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = ga->c; a.Hg = ga->h; a.Wg = ga->w;
+  inj_patch_th(a.H, a.W, a.Hg, a.Wg, INJ2_TH, &a.PH, &a.PW);
+  a.tiles_x = cdiv(a.W, INJ_TW); a.tiles_y = cdiv(a.H, INJ2_TH);
+  A.w2 = (const char*)packed_w2; A.bias2 = bias2; A.act2 = act2; A.C2 = y2->c;
+  A.y2 = (char*)y2->p; A.y2sn = (int)(y2->sn * sz); A.y2sh = (int)(y2->sh * sz); A.y2sw = (int)(y2->sw * sz); A.y2_bytes = (uint32_t)ext(y2);
+  const int kc = inj_kc(a.Cin), nb2 = cdiv(y2->c, 16);
+  const size_t lds = inj2_lds(kc, 16, nb2, a.PH, a.PW);
+  hipStream_t st = (hipStream_t)s;
+#define INJ2_CASE(K, B) if (kc == K && nb2 == B) return inj2_launch<K, B>(A, lds, st);
+  INJ2_CASE(1, 1) INJ2_CASE(1, 2) INJ2_CASE(1, 3) INJ2_CASE(1, 4) INJ2_CASE(2, 1) INJ2_CASE(2, 2) INJ2_CASE(2, 3) INJ2_CASE(2, 4)
+  INJ2_CASE(3, 1) INJ2_CASE(3, 2) INJ2_CASE(3, 3) INJ2_CASE(3, 4) INJ2_CASE(4, 1) INJ2_CASE(4, 2) INJ2_CASE(4, 3) INJ2_CASE(4, 4)
+#undef INJ2_CASE
+  MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: no kernel for kc=%d nb2=%d", kc, nb2);
 }

@@ -85,7 +85,21 @@ class C2f(HipModule):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    def forward(self, x):
+    def forward(self, x, head=None):
+        """`head` (the model's plan, eval only): (injection module, its inputs) when this block's input is that injection's output and
+        nobody else reads it - cv1 then runs inside the injection launch (mgdt_conv1x1_inject_conv_fwd) and `x` is None."""
+        if head is not None:
+            x_l = head[1][0]
+            dt0 = self.cv1.out_dtype(x_l)
+            ok = (not (self.training and hasattr(self.cv1, 'bn')) and _plain_block(self.cv1, self.cv2, self.m) and ops.csp_block_supported(
+                ops.CSP_C2F, ops.new_act(x_l.shape[0], 2 * self.c, x_l.shape[2], x_l.shape[3], dt0, x_l.device), self.cv2.conv.out_channels, self.c, len(self.m), dt0))
+            y01 = head[0].forward_into_conv(head[1], self.cv1) if ok else None
+            if y01 is None:
+                x = head[0](head[1])                         # not covered after all: the injection's own launch
+            else:
+                mids = [pk for m in self.m for pk in (m.cv1.packed(y01.dtype, False), m.cv2.packed(y01.dtype, False))]
+                return ops.csp_block(ops.CSP_C2F, y01, None, None, mids, self.m[0].add, self.cv2.packed(y01.dtype, False), self.c, act_code(self.cv1.act),
+                                     self.cv2.conv.out_channels, False)[0]
         b, _, h, w = x.shape
         c, n = self.c, len(self.m)
         train = self.training and hasattr(self.cv1, 'bn')
@@ -420,6 +434,40 @@ class InjectionMultiSum_Auto_pool(HipModule):
         if xq is not None:      # the e4m3 panel of the same merged convolution (quantize_fp8)
             return self._cached(('gaf', 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), None, bn(), 1, xq))
         return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), None, bn(), 1, dt))
+
+    def forward_into_conv(self, x, conv):
+        """Injection + the 1x1 Conv+BN+act `conv` that consumes it (C2f.cv1) in one launch; returns conv's output, or None when the pair is
+        not covered (the caller then runs the two modules as usual).  Eval, bf16, up-sampling branch only."""
+        x_l, x_g = x
+        le = self.local_embedding
+        if self.training or not isinstance(conv, Conv) or not hasattr(conv, 'bn') or not hasattr(le, 'bn'):
+            return None
+        if ops.Q8_CALIB is not None or self.__dict__.get('_q8') or conv.__dict__.get('_q8') or le.__dict__.get('_q8'):
+            return None                                      # fp8 calibration / fp8 operands: the per-site path
+        dt = le.out_dtype(x_l)
+        c0 = sum(self.global_inp[:self.flag])
+        g = x_g[:, c0:c0 + self.global_inp[self.flag]]
+        pk2g = self._merged_global(g)
+        if (pk2g is None or dt != torch.bfloat16 or act_code(le.act) != ops.ACT_NONE or le.conv.kernel_size != (1, 1)
+                or le.conv.groups != 1 or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1) or conv.conv.groups != 1 or conv.conv.bias is not None
+                or conv.conv.in_channels != le.conv.out_channels):
+            return None
+        oc = self.global_act.conv.out_channels
+        b, _, h, w = x_l.shape
+        gh, gw = g.shape[2], g.shape[3]
+        probe = ops.new_act(1, oc, gh, gw, dt, x_l.device)
+        if not ops.conv1x1_inject_conv_supported(x_l, oc, conv.conv.out_channels, probe, dt):
+            return None
+        gaf = ops.conv2d(g, pk2g, 1, ops.ACT_NONE)
+        ga, gf = gaf[:, :oc], gaf[:, oc:]
+        if ga.stride() != gf.stride():
+            return None
+        tens = [conv.conv.weight, conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var]
+        pk2 = conv._cached(('acc_order', dt), tens, lambda: ops.PackedConv(
+            conv.conv.weight.detach()[:, ops.acc_order_index(conv.conv.in_channels, conv.conv.weight.device)], None,
+            (conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var, conv.bn.eps), 1, dt))
+        out = ops.new_act(b, conv.conv.out_channels, h, w, dt, x_l.device)
+        return ops.conv1x1_inject_conv(x_l, le.packed(dt, direct=False), ga, gf, pk2, act_code(conv.act), out)
 
     def forward(self, x):
         x_l, x_g = x

@@ -91,10 +91,17 @@ class BaseModel(nn.Module):
             layers = list(self.model)[2:]
         plan = self._neck_plan(x) if not self.training else None
         bufs = {}                                           # consumer layer -> {'out': concat buffer, 'done': slots, 'pooled0': ...}
+        head = None                                         # (injection module, its inputs) waiting for the C2f block behind it
         for m in layers:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            if plan is not None and m.i in plan['producers']:
+            if head is not None:                            # the injection in front of this C2f runs inside this block's first launch
+                x, head = m(None, head=head), None
+            elif self._injection_feeds_next(m):
+                head = (m, x)
+                y.append(None)
+                continue
+            elif plan is not None and m.i in plan['producers']:
                 x = m(x, deliver=self._neck_deliveries(plan, m, x, bufs))
             elif plan is not None and m.i in plan['consumers']:
                 x = m(x, pre=bufs.get(m.i))
@@ -102,6 +109,15 @@ class BaseModel(nn.Module):
                 x = m(x)
             y.append(x if m.i in self.save else None)
         return x
+
+    def _injection_feeds_next(self, m):
+        """layer m is an InjectionMultiSum_Auto_pool whose only consumer is the C2f right behind it (bf16 inference, no hooks): the pair runs
+        as injection + C2f.cv1 in one launch, then the block kernel (mgdt_conv1x1_inject_conv_fwd)."""
+        if (self.training or not ops.FUSED_INJECT_CONV or getattr(self, 'compute_dtype', None) != torch.bfloat16 or not isinstance(m, InjectionMultiSum_Auto_pool)
+                or m.i in self.save or m.i + 1 >= len(self.model)):
+            return False
+        nxt = self.model[m.i + 1]
+        return isinstance(nxt, C2f) and nxt.f == -1 and not m._forward_hooks and not nxt._forward_hooks and len(nxt.m) >= 1
 
     # -- GD-neck data movement folded into the producers (SURVEY section 7 step 4; VERDICT r2 item 4) ------------------------------------
     def _neck_plan(self, x):

@@ -364,8 +364,13 @@ CSP_MSPA, CSP_C2F = 0, 1
 
 
 def csp_block_supported(mode, x, cout, wd, nbtl, dtype):
-    return bool(FUSED_CSP_BLOCK and dtype == torch.bfloat16 and x.dtype == dtype and is_nhwc(x) and
-                L.lib().mgdt_csp_block_supported(mode, x.shape[1], int(cout), int(wd), int(nbtl), x.shape[2], x.shape[3], dtype_code(dtype)))
+    """channel counts / dtype covered AND a tile decomposition exists for this map (tiles must divide it: none for e.g. a 37-row map)"""
+    if not (FUSED_CSP_BLOCK and dtype == torch.bfloat16 and x.dtype == dtype and is_nhwc(x)):
+        return False
+    lib = L.lib()
+    if not lib.mgdt_csp_block_supported(mode, x.shape[1], int(cout), int(wd), int(nbtl), x.shape[2], x.shape[3], dtype_code(dtype)):
+        return False
+    return lib.mgdt_csp_block_tiles(mode, x.shape[0], x.shape[1], int(cout), int(wd), int(nbtl), x.shape[2], x.shape[3], None) > 0
 
 
 def csp_block(mode, x, front, front_bias, mids, shortcut, back, wd, act, cout, want_pool):
@@ -544,6 +549,35 @@ FUSED_INJECT = True     # tests flip this to compare against conv + inject
 def conv1x1_inject_supported(x, cout, ga, dtype):
     return bool(FUSED_INJECT and x.dtype == dtype and ga.dtype == dtype and is_nhwc(x) and is_nhwc(ga) and
                 L.lib().mgdt_conv1x1_inject_supported(x.shape[1], cout, x.shape[2], x.shape[3], ga.shape[2], ga.shape[3], dtype_code(dtype)))
+
+
+def acc_order_index(c, device):
+    """Input-channel permutation that turns an ordinary packed 1x1 panel into one whose K runs in the MFMA ACCUMULATOR order of the conv in
+    front of it: packed channel (j*4 + g)*8 + e <- channel (2*j + e//4)*16 + 4*g + e%4."""
+    k = torch.arange(c, device=device)
+    j, g, e = k // 32, (k // 8) % 4, k % 8
+    return (2 * j + e // 4) * 16 + 4 * g + e % 4
+
+
+def conv1x1_inject_conv_supported(x, cmid, cout2, ga, dtype):
+    return bool(FUSED_INJECT and FUSED_INJECT_CONV and x.dtype == dtype and ga.dtype == dtype and is_nhwc(x) and is_nhwc(ga) and
+                L.lib().mgdt_conv1x1_inject_conv_supported(x.shape[1], cmid, cout2, x.shape[2], x.shape[3], ga.shape[2], ga.shape[3], dtype_code(dtype)))
+
+
+def conv1x1_inject_conv(x, pk, ga, gf, pk2, act2, out):
+    """out = act2(conv1x1_2(conv1x1(x) * bilinear(h_sigmoid(ga)) + bilinear(gf))) in one launch (mgdt_conv1x1_inject_conv_fwd); pk2: the second
+    conv packed with its input channels in `acc_order_index` order."""
+    b, _, h, w = x.shape
+    _same(x, ga, gf, out)
+    if _PROF is not None:
+        _META['conv1x1_inject_conv_fwd'] = dict(shape=(b, pk.cin, h, w, pk2.cout, 1, 1), flops=2.0 * b * h * w * (pk.cout * pk.cin + pk2.cout * pk2.cin),
+                                                bytes=float(b * h * w * (pk.cin + pk2.cout) * x.element_size() + 2 * ga.numel() * ga.element_size()))
+    _launch('conv1x1_inject_conv_fwd', 'mgdt_conv1x1_inject_conv_fwd', vp(x), ptr(pk.w), ptr(pk.bias), vp(ga), vp(gf), ptr(pk2.w), ptr(pk2.bias), int(act2), vp(out),
+            dtype_code(pk.dtype), stream())
+    return out
+
+
+FUSED_INJECT_CONV = True   # tests flip this: injection + C2f.cv1 in one launch vs two
 
 
 def conv1x1_inject(x, pk, ga, gf, out=None):

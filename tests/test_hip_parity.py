@@ -295,6 +295,41 @@ def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
     assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('b,hw,ghw', [(32, (80, 80), (40, 40)), (2, (37, 45), (19, 23)), (3, (16, 16), (16, 16)), (1, (80, 80), (20, 20))])
+def test_injection_plus_c2f_cv1_single_launch_matches_two_launches(b, hw, ghw):
+    """mgdt_conv1x1_inject_conv_fwd: the injection and the 1x1 Conv+BN+SiLU that is its only consumer (C2f.cv1) in one launch - the
+    256-channel map goes from the first GEMM's accumulators through the bilinear tail into the second GEMM's B operand (rounded to bf16 where
+    the stored map would be).  Against injection launch + conv launch: same roundings, a different fp32 summation order over the 256 input
+    channels of the second conv -> agreement to bf16 resolution (1.5e-2 of the largest output).  Odd sizes, equal sizes (no up-sampling), x4."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import C2f, InjectionMultiSum_Auto_pool
+    inj = seed_state_dict_(InjectionMultiSum_Auto_pool(64, 256, [64, 32], 1), 3).eval().to(DEV)
+    c2f = seed_state_dict_(C2f(256, 64, 1, False), 4).eval().to(DEV)
+    for mod in (inj, c2f):
+        mod.apply(lambda t: setattr(t, '_cdtype', torch.bfloat16) if hasattr(t, 'out_dtype') else None)
+    gen = torch.Generator().manual_seed(7)
+    mk = lambda c, s: torch.randn(b, c, *s, generator=gen).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x_l, x_g = mk(64, hw), mk(96, ghw)
+    with torch.no_grad():
+        y_fused = c2f(None, head=(inj, [x_l, x_g])).float()
+        ops.FUSED_INJECT_CONV = False
+        try:
+            y_two = c2f(inj([x_l, x_g])).float()
+        finally:
+            ops.FUSED_INJECT_CONV = True
+        y01_f = inj.forward_into_conv([x_l, x_g], c2f.cv1)
+        y01_t = c2f.cv1(inj([x_l, x_g])).float()
+        if ghw == hw:            # no up-sampling: the source patches of an 8 x 16 tile do not fit LDS next to both panels -> the two-launch form by itself
+            assert y01_f is None
+            y01_f = y01_t
+        assert y01_f is not None, 'the fused launch must cover these shapes'
+        y01_f = y01_f.float()
+    s1, s2 = y01_t.abs().max().item(), y_two.abs().max().item()
+    e1, e2 = (y01_f - y01_t).abs().max().item(), (y_fused - y_two).abs().max().item()
+    print(f'inject+cv1 {b}x{hw}<-{ghw}: cv1 output err {e1 / s1:.2e} of {s1:.2f}, block output err {e2 / s2:.2e} of {s2:.2f}')
+    assert e1 < 1.5e-2 * s1 and e2 < 3e-2 * s2
+
+
 @pytest.mark.parametrize('nc,ch,hws', [(80, (64,), [(80, 80)]), (4, (64,), [(13, 11)]), (3, (64,), [(9, 5)]), (80, (64, 128, 256), [(20, 24), (10, 12), (5, 6)]), (20, (32,), [(7, 9)])])
 def test_detect_tail_single_launch_matches_conv_conv_decode(nc, ch, hws):
     """bf16: mgdt_detect_tail_fwd (both final 1x1 convs + raw map + DFL / dist2bbox / sigmoid decode) vs mgdt_conv2d_fwd x2 + mgdt_detect_decode_fwd.
