@@ -303,6 +303,55 @@ extern "C" int mgdt_spr_attn_fwd(const float* pooled, const float* fc1_w, const 
 // where the GD neck's SimFusion modules would otherwise launch their own pooling kernels (nn/modules/block.py:289-329)
 struct SprPool { void* y; long sn, sh, sw; int F; };
 
+// Scaling pass in FM x FM pixel cells (FM = the largest pooling factor asked for, 2 or 4): a thread owns one cell x V channels, has all its
+// FM*FM vectors in flight at once, scales / rounds / stores them in row-major order and accumulates the pooled sums on the way - the FM x FM
+// pool of the cell and (FM = 4) its four 2 x 2 pools, each in the row-major order of mgdt_adaptive_avgpool_fwd, so the pooled maps are
+// bit-equal to pooling the stored map.  No second pass over the map (the re-reading form cost as much as the pooling launches it replaced).
+template <typename T, int V, int FM>
+__device__ __forceinline__ void spr_scale_cells(const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh, long ysw,
+                                                const float* att, int n, int H, int W, int C, SprPool big, SprPool small) {
+  const int Q = C / V, Hc = H / FM, Wc = W / FM, NC = Hc * Wc;
+  const int c0 = (int)((long)blockIdx.x * NC / gridDim.x), c1 = (int)((long)(blockIdx.x + 1) * NC / gridDim.x);
+  for (int j = threadIdx.x; j < (c1 - c0) * Q; j += 256) {
+    const int cl = j / Q, q = j - cl * Q, cell = c0 + cl, cy = cell / Wc, cx = cell - cy * Wc;
+    float a[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) a[k] = att[q * V + k];
+    float v[FM * FM][V];
+#pragma unroll
+    for (int e = 0; e < FM * FM; ++e) ldv<T, V>(x + n * xsn + (long)(cy * FM + e / FM) * xsh + (long)(cx * FM + e % FM) * xsw + q * V, v[e]);
+    float accb[V], accs[4][V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { accb[k] = 0.f; accs[0][k] = accs[1][k] = accs[2][k] = accs[3][k] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < FM * FM; ++e) {
+      const int yy = e / FM, xx = e % FM;
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[e][k] = (float)(T)(v[e][k] * a[k]);              // the value the map stores
+      stv<T, V>(y + n * ysn + (long)(cy * FM + yy) * ysh + (long)(cx * FM + xx) * ysw + q * V, v[e]);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        accb[k] += v[e][k];
+        if (FM == 4) accs[(yy >> 1) * 2 + (xx >> 1)][k] += v[e][k];
+      }
+    }
+    if (big.F) {
+      const float inv = 1.f / (float)(FM * FM);
+#pragma unroll
+      for (int k = 0; k < V; ++k) accb[k] *= inv;
+      stv<T, V>((T*)big.y + n * big.sn + cy * big.sh + cx * big.sw + q * V, accb);
+    }
+    if (FM == 4 && small.F) {
+#pragma unroll
+      for (int sc = 0; sc < 4; ++sc) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) accs[sc][k] *= 0.25f;
+        stv<T, V>((T*)small.y + n * small.sn + (long)(cy * 2 + (sc >> 1)) * small.sh + (long)(cx * 2 + (sc & 1)) * small.sw + q * V, accs[sc]);
+      }
+    }
+  }
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
@@ -383,6 +432,18 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
     for (int gi = 0; gi < G; ++gi) att[gi * cw + c] = expf(obuf[gi * cw + c] - mx) / den;
   }
   __syncthreads();
+  {
+    // pooled outputs with factors {4}, {2}, {4, 2}: the cell form does everything in one pass
+    const int fa = pa.F, fb = pb.F, fm = max(fa, fb);
+    const bool cells = fm > 0 && (fm == 2 || fm == 4) && (fa == 0 || fa == fm || (fm == 4 && fa == 2)) && (fb == 0 || fb == fm || (fm == 4 && fb == 2)) && !(fa == fb);
+    if (cells) {
+      const SprPool none = {nullptr, 0, 0, 0, 0};
+      const SprPool big = fa == fm ? pa : (fb == fm ? pb : none), small = (fa && fa < fm) ? pa : ((fb && fb < fm) ? pb : none);
+      if (fm == 4) spr_scale_cells<T, V, 4>(x, xsn, xsh, xsw, y, ysn, ysh, ysw, att, n, H, W, C, big, small);
+      else spr_scale_cells<T, V, 2>(x, xsn, xsh, xsw, y, ysn, ysh, ysw, att, n, H, W, C, big, small);
+      return;
+    }
+  }
   const int Q = C / V, HW = H * W;
   const int p0 = (int)((long)blockIdx.x * HW / gridDim.x), p1 = (int)((long)(blockIdx.x + 1) * HW / gridDim.x);
   const uint32_t total = (uint32_t)(p1 - p0) * Q;
