@@ -178,9 +178,13 @@ int mgdt_conv1x1_inject_fwd(const mgdt_view* x, const void* packed_w, const floa
 /* ---- injection + the NEXT layer's 1x1 Conv+BN+act in one launch (models/v8/mspa_c2f_gd_yolov8.yaml head rows 4-5: the injection's 256-channel
  * output has one consumer, C2f.cv1, nn/modules/block.py:199-201): y2 = act2(conv1x1(injection(x, ga, gf)) + bias2), the 256-channel map never
  * leaves the chip.  packed_w2 / bias2: mgdt_conv_pack(256, cout2, 1, bf16) of the second conv with its INPUT channels permuted to the first
- * conv's accumulator order: packed input channel (j*4 + g)*8 + e <- channel (2*j + e/4)*16 + 4*g + e%4 (j < 8, g < 4, e < 8). */
+ * conv's accumulator order: packed input channel (j*4 + g)*8 + e <- channel (2*j + e/4)*16 + 4*g + e%4 (j < 8, g < 4, e < 8).
+ * Global maps: either ga / gf (computed by the caller; gsrc NULL) or gsrc = their common 32-channel input (block.py:377-381: x_g.split(...)[flag])
+ * with packed_wg / bias_g = mgdt_conv_pack(32, 2 * cmid, 1, bf16) of [global_act | global_embedding] (cmid = 256): both 1x1 convs are then
+ * evaluated on each tile's source pixels inside this launch and the 2 x cmid-channel maps never reach HBM either (ga / gf NULL). */
 int mgdt_conv1x1_inject_conv_supported(int cin, int cmid, int cout2, int h, int w, int hg, int wg, int dtype);
 int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+                                 const mgdt_view* gsrc, const void* packed_wg, const float* bias_g, int cmid,
                                  const void* packed_w2, const float* bias2, int act2, const mgdt_view* y2, int dtype, mgdt_stream s);
 
 /* ---- TOODHead (nn/modules/head.py:466-572; parity unpinned: mmcv's ModulatedDeformConv2d is not shipped with the reference) --------

@@ -72,7 +72,7 @@ PROTOTYPES = {
     'mgdt_conv1x1_inject_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'mgdt_conv1x1_inject_fwd': (_i, [VP, _vp, _vp, VP, VP, VP, _i, _vp]),
     'mgdt_conv1x1_inject_conv_supported': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    'mgdt_conv1x1_inject_conv_fwd': (_i, [VP, _vp, _vp, VP, VP, _vp, _vp, _i, VP, _i, _vp]),
+    'mgdt_conv1x1_inject_conv_fwd': (_i, [VP, _vp, _vp, VP, VP, VP, _vp, _vp, _i, _vp, _vp, _i, VP, _i, _vp]),
     'mgdt_spr_attn_scale_fwd': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, VP, VP, VP, VP, _i, _vp]),
     'mgdt_stem2_packed_bytes': (_sz, []),
     'mgdt_stem2_pack': (_i, [_vp, _vp, _vp]),

@@ -139,12 +139,14 @@ __global__ __launch_bounds__(INJ_THREADS) void conv1x1_inject_kernel(const InjAr
 // x (64 ch) + the two global maps in, 64 channels out.  Workgroup = TH waves = a TH x 16 patch; both panels + both source patches in LDS.
 struct InjConvArgs {
   InjArgs a;
+  const char* gx; int gxsn, gxsh, gxsw; uint32_t gx_bytes;   // GCONV: the 32-channel global input the two global convs read (ga / gf are then computed here)
+  const char* wg; const float* bias_g;                       // GCONV: merged panel [global_act | global_embedding] 32 -> 2 * Cout, mgdt_conv_pack layout
   const char* w2; const float* bias2;      // 1x1 panel of the second conv with its K (= Cout of the injection) in ACCUMULATOR order, BN folded
   char* y2; int y2sn, y2sh, y2sw; uint32_t y2_bytes;
   int C2, act2;
 };
 
-template <int KC, int NB, int NB2, int TH>
+template <int KC, int NB, int NB2, int TH, bool GCONV>
 __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjConvArgs A) {
   typedef bf16 T;
   typedef bf16x8 frag;
@@ -166,6 +168,20 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)A.y2, 0, A.y2_bytes, 0x00020000);
   const char* const wlane = wl + lane * 16;
   const char* const w2lane = w2l + lane * 16;
+  // GCONV: global_act and global_embedding (two 1x1 Conv+BN, no activation, 32 -> NB*16 channels each; block.py:379-381) are evaluated here on the
+  // patch's source pixels instead of being read back from HBM: this wave owns 2*NB/TH of the 2*NB cout blocks, weights in registers
+  static_assert(!GCONV || (2 * NB) % TH == 0, "cout blocks per wave");
+  constexpr int GB = GCONV ? (2 * NB) / TH : 1;
+  bf16x8 Ag[GB];
+  f32x4 bg[GB];
+  if (GCONV) {
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+      Ag[t] = *(const bf16x8*)(A.wg + ((size_t)(wave * GB + t) * 64 + lane) * 16);
+      bg[t] = *(const f32x4*)(A.bias_g + (wave * GB + t) * 16 + 4 * g);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(GCONV ? A.gx : a.x), 0, GCONV ? A.gx_bytes : 0u, 0x00020000);
   const int npatch = a.N * a.tiles_x * a.tiles_y;
 #pragma unroll 1
   for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
@@ -188,7 +204,26 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
     inj_lerp(min(tx * INJ_TW + INJ_TW - 1, a.W - 1), a.Wg, a.W, t0, px1, tl);
     const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;
     __syncthreads();                                       // the previous patch's tail is done with the LDS maps
-    {
+    if (GCONV) {
+      const int npx = ph * pw;
+      for (int grp = 0; grp * 16 < npx; ++grp) {
+        const int p = grp * 16 + r;
+        const bool v_ = p < npx;
+        const int sy = (v_ ? p : 0) / pw, sx = (v_ ? p : 0) - sy * pw;
+        const uint32_t go = v_ ? (uint32_t)(n * A.gxsn + (py0 + sy) * A.gxsh + (px0 + sx) * A.gxsw + g * 16) : (uint32_t)MGDT_OOB;
+        const frag Bg = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(grs, go, 0, 0));      // 32 input channels = one K chunk
+#pragma unroll
+        for (int t = 0; t < GB; ++t) {
+          const int nbg = wave * GB + t;                    // uniform
+          const f32x4 o = mma(Ag[t], Bg, bg[t]);
+          bf16x4 ob;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ob[i] = (bf16)o[i];   // the stored (rounded) global maps
+          T* dst = (nbg < NB ? sg : sf) + (size_t)p * CS + (nbg % NB) * 16 + 4 * g;
+          if (v_) *(bf16x4*)dst = ob;
+        }
+      }
+    } else {
       constexpr int VPP = NB * 16 / 8;
       const int nvec = ph * pw * VPP;
       for (int i = tid; i < nvec; i += THREADS) {
@@ -354,22 +389,35 @@ extern "C" int mgdt_conv1x1_inject_conv_supported(int cin, int cmid, int cout2, 
   return inj2_lds(inj_kc(cin), cmid / 16, cout2 / 16, PH, PW) <= 156 * 1024;
 }
 
-template <int KC, int NB2>
+template <int KC, int NB2, bool GCONV>
 static int inj2_launch(const InjConvArgs& A, size_t lds, hipStream_t st) {
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH, GCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "conv1x1_inject_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH><<<std::min(A.a.N * A.a.tiles_x * A.a.tiles_y, 256), 64 * INJ2_TH, lds, st>>>(A);   // persistent: one per CU
+  conv1x1_inject_conv_kernel<KC, 16, NB2, INJ2_TH, GCONV><<<std::min(A.a.N * A.a.tiles_x * A.a.tiles_y, 256), 64 * INJ2_TH, lds, st>>>(A);   // persistent: one per CU
   MGDT_CHECK_LAUNCH("conv1x1_inject_conv_fwd");
   return MGDT_OK;
 }
 
-extern "C" int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga, const mgdt_view* gf,
+extern "C" int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* packed_w, const float* bias, const mgdt_view* ga_in, const mgdt_view* gf_in,
+                                            const mgdt_view* gsrc, const void* packed_wg, const float* bias_g, int cmid,
                                             const void* packed_w2, const float* bias2, int act2, const mgdt_view* y2, int dtype, mgdt_stream s) {
-  if (!view_ok(x) || !view_ok(ga) || !view_ok(gf) || !view_ok(y2) || !packed_w || !bias || !packed_w2 || !bias2) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject_conv: null/empty argument");
+  // two forms: (ga, gf) = the global act / embedding maps computed by the caller, or (gsrc, packed_wg, bias_g, cmid) = their common 32-channel
+  // input + the merged panel [global_act | global_embedding] (mgdt_conv_pack(32, 2 * cmid, 1, bf16)): the maps are then evaluated per tile
+  const bool gconv = gsrc && gsrc->p;
+  mgdt_view gav, gfv;
+  if (gconv) {
+    if (!view_ok(gsrc) || !packed_wg || !bias_g || gsrc->c != 32 || cmid != 256) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject_conv: global source must be a 32-channel view with its merged panel (cmid 256)");
+    gav = *gsrc; gav.c = cmid; gfv = gav;                   // geometry only (n, h, w): the kernel never dereferences ga / gf in this form
+  } else {
+    if (!view_ok(ga_in) || !view_ok(gf_in)) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject_conv: null/empty global maps");
+    gav = *ga_in; gfv = *gf_in;
+  }
+  const mgdt_view* ga = &gav; const mgdt_view* gf = &gfv;
+  if (!view_ok(x) || !view_ok(y2) || !packed_w || !bias || !packed_w2 || !bias2) MGDT_FAIL(MGDT_BAD_ARG, "conv1x1_inject_conv: null/empty argument");
   if (!mgdt_conv1x1_inject_conv_supported(x->c, ga->c, y2->c, x->h, x->w, ga->h, ga->w, dtype))
     MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: shapes/dtype not covered (see mgdt_conv1x1_inject_conv_supported)");
   const long sz = 2;
@@ -378,11 +426,17 @@ extern "C" int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* pack
     MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: x/y2 spatial sizes, ga/gf shapes and layouts must match");
   auto ok = [&](const mgdt_view* v, int q) { return v->sc == 1 && v->sw % q == 0 && v->sh % q == 0 && v->sn % q == 0 && (uintptr_t)v->p % (q * sz) == 0; };
   auto ext = [&](const mgdt_view* v) { return ((long)(v->n - 1) * v->sn + (long)(v->h - 1) * v->sh + (long)(v->w - 1) * v->sw + v->c) * sz; };
-  if (!ok(x, 8) || !ok(ga, 8) || !ok(gf, 8) || !ok(y2, 4) || ext(x) >= 0x7fffffffL || ext(y2) >= 0x7fffffffL)
+  if (!ok(x, 8) || (!gconv && (!ok(ga, 8) || !ok(gf, 8))) || (gconv && (!ok(gsrc, 8) || ((long)(gsrc->n - 1) * gsrc->sn + (long)(gsrc->h - 1) * gsrc->sh + (long)(gsrc->w - 1) * gsrc->sw + gsrc->c) * sz >= 0x7fffffffL)) ||
+      !ok(y2, 4) || ext(x) >= 0x7fffffffL || ext(y2) >= 0x7fffffffL)
     MGDT_FAIL(MGDT_BAD_SHAPE, "conv1x1_inject_conv: views must be aligned NHWC (sc == 1) and < 2 GiB");
   InjConvArgs A;
   memset(&A, 0, sizeof(A));
   InjArgs& a = A.a;
+  if (gconv) {
+    A.gx = (const char*)gsrc->p; A.gxsn = (int)(gsrc->sn * sz); A.gxsh = (int)(gsrc->sh * sz); A.gxsw = (int)(gsrc->sw * sz);
+    A.gx_bytes = (uint32_t)(((long)(gsrc->n - 1) * gsrc->sn + (long)(gsrc->h - 1) * gsrc->sh + (long)(gsrc->w - 1) * gsrc->sw + gsrc->c) * sz);
+    A.wg = (const char*)packed_wg; A.bias_g = bias_g;
+  }
   a.x = (const char*)x->p; a.xsn = (int)(x->sn * sz); a.xsh = (int)(x->sh * sz); a.xsw = (int)(x->sw * sz); a.x_bytes = (uint32_t)ext(x);
   a.ga = (const char*)ga->p; a.gf = (const char*)gf->p; a.gsn = (int)(ga->sn * sz); a.gsh = (int)(ga->sh * sz); a.gsw = (int)(ga->sw * sz);
   a.wpk = (const char*)packed_w; a.bias = bias;
@@ -394,7 +448,7 @@ extern "C" int mgdt_conv1x1_inject_conv_fwd(const mgdt_view* x, const void* pack
   const int kc = inj_kc(a.Cin), nb2 = cdiv(y2->c, 16);
   const size_t lds = inj2_lds(kc, 16, nb2, a.PH, a.PW);
   hipStream_t st = (hipStream_t)s;
-#define INJ2_CASE(K, B) if (kc == K && nb2 == B) return inj2_launch<K, B>(A, lds, st);
+#define INJ2_CASE(K, B) if (kc == K && nb2 == B) return gconv ? inj2_launch<K, B, true>(A, lds, st) : inj2_launch<K, B, false>(A, lds, st);
   INJ2_CASE(1, 1) INJ2_CASE(1, 2) INJ2_CASE(1, 3) INJ2_CASE(1, 4) INJ2_CASE(2, 1) INJ2_CASE(2, 2) INJ2_CASE(2, 3) INJ2_CASE(2, 4)
   INJ2_CASE(3, 1) INJ2_CASE(3, 2) INJ2_CASE(3, 3) INJ2_CASE(3, 4) INJ2_CASE(4, 1) INJ2_CASE(4, 2) INJ2_CASE(4, 3) INJ2_CASE(4, 4)
 #undef INJ2_CASE

@@ -458,15 +458,19 @@ class InjectionMultiSum_Auto_pool(HipModule):
         probe = ops.new_act(1, oc, gh, gw, dt, x_l.device)
         if not ops.conv1x1_inject_conv_supported(x_l, oc, conv.conv.out_channels, probe, dt):
             return None
-        gaf = ops.conv2d(g, pk2g, 1, ops.ACT_NONE)
-        ga, gf = gaf[:, :oc], gaf[:, oc:]
-        if ga.stride() != gf.stride():
-            return None
+        in_launch = g.shape[1] == 32 and oc == 256 and ops.FUSED_INJECT_GCONV        # the two global convs run inside the launch too
+        if not in_launch:
+            gaf = ops.conv2d(g, pk2g, 1, ops.ACT_NONE)
+            ga, gf = gaf[:, :oc], gaf[:, oc:]
+            if ga.stride() != gf.stride():
+                return None
         tens = [conv.conv.weight, conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var]
         pk2 = conv._cached(('acc_order', dt), tens, lambda: ops.PackedConv(
             conv.conv.weight.detach()[:, ops.acc_order_index(conv.conv.in_channels, conv.conv.weight.device)], None,
             (conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var, conv.bn.eps), 1, dt))
         out = ops.new_act(b, conv.conv.out_channels, h, w, dt, x_l.device)
+        if in_launch:
+            return ops.conv1x1_inject_conv(x_l, le.packed(dt, direct=False), None, None, pk2, act_code(conv.act), out, gsrc=g, pkg=pk2g)
         return ops.conv1x1_inject_conv(x_l, le.packed(dt, direct=False), ga, gf, pk2, act_code(conv.act), out)
 
     def forward(self, x):

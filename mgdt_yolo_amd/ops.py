@@ -564,20 +564,22 @@ def conv1x1_inject_conv_supported(x, cmid, cout2, ga, dtype):
                 L.lib().mgdt_conv1x1_inject_conv_supported(x.shape[1], cmid, cout2, x.shape[2], x.shape[3], ga.shape[2], ga.shape[3], dtype_code(dtype)))
 
 
-def conv1x1_inject_conv(x, pk, ga, gf, pk2, act2, out):
+def conv1x1_inject_conv(x, pk, ga, gf, pk2, act2, out, gsrc=None, pkg=None):
     """out = act2(conv1x1_2(conv1x1(x) * bilinear(h_sigmoid(ga)) + bilinear(gf))) in one launch (mgdt_conv1x1_inject_conv_fwd); pk2: the second
-    conv packed with its input channels in `acc_order_index` order."""
+    conv packed with its input channels in `acc_order_index` order.  With (gsrc, pkg) instead of (ga, gf): the two global 1x1 convs (merged
+    panel pkg over the 32-channel gsrc) run inside the launch as well."""
     b, _, h, w = x.shape
-    _same(x, ga, gf, out)
+    _same(x, ga, gf, gsrc, out)
     if _PROF is not None:
         _META['conv1x1_inject_conv_fwd'] = dict(shape=(b, pk.cin, h, w, pk2.cout, 1, 1), flops=2.0 * b * h * w * (pk.cout * pk.cin + pk2.cout * pk2.cin),
-                                                bytes=float(b * h * w * (pk.cin + pk2.cout) * x.element_size() + 2 * ga.numel() * ga.element_size()))
-    _launch('conv1x1_inject_conv_fwd', 'mgdt_conv1x1_inject_conv_fwd', vp(x), ptr(pk.w), ptr(pk.bias), vp(ga), vp(gf), ptr(pk2.w), ptr(pk2.bias), int(act2), vp(out),
-            dtype_code(pk.dtype), stream())
+                                                bytes=float(b * h * w * (pk.cin + pk2.cout) * x.element_size() + (2 * ga.numel() * ga.element_size() if gsrc is None else gsrc.numel() * 2)))
+    _launch('conv1x1_inject_conv_fwd', 'mgdt_conv1x1_inject_conv_fwd', vp(x), ptr(pk.w), ptr(pk.bias), vp(ga), vp(gf), vp(gsrc), None if pkg is None else ptr(pkg.w),
+            None if pkg is None else ptr(pkg.bias), pk.cout, ptr(pk2.w), ptr(pk2.bias), int(act2), vp(out), dtype_code(pk.dtype), stream())
     return out
 
 
 FUSED_INJECT_CONV = True   # tests flip this: injection + C2f.cv1 in one launch vs two
+FUSED_INJECT_GCONV = True  # ... and the injection's two global 1x1 convs inside that launch vs a launch of their own
 
 
 def conv1x1_inject(x, pk, ga, gf, out=None):

@@ -318,6 +318,12 @@ def test_injection_plus_c2f_cv1_single_launch_matches_two_launches(b, hw, ghw):
         finally:
             ops.FUSED_INJECT_CONV = True
         y01_f = inj.forward_into_conv([x_l, x_g], c2f.cv1)
+        ops.FUSED_INJECT_GCONV = False                         # the global convs as a launch of their own: identical values
+        try:
+            y01_g = inj.forward_into_conv([x_l, x_g], c2f.cv1)
+        finally:
+            ops.FUSED_INJECT_GCONV = True
+        assert (y01_f is None) == (y01_g is None) and (y01_f is None or torch.equal(y01_f, y01_g))
         y01_t = c2f.cv1(inj([x_l, x_g])).float()
         if ghw == hw:            # no up-sampling: the source patches of an 8 x 16 tile do not fit LDS next to both panels -> the two-launch form by itself
             assert y01_f is None
