@@ -111,11 +111,15 @@ int mgdt_cnx_mlp_fwd(const mgdt_view* t, const mgdt_view* res, const void* packe
  * mgdt_cnx_mlp_pack.  ws (mgdt_cnx_block_workspace_bytes, 16-byte aligned): its first 4096 bytes are the per-image barrier words (arrival
  * counter + generation) that MUST BE ZERO at the first call and belong to this function from then on (the counters are back at zero when a
  * call ends, so hipGraph replays and calls with other shapes need no reset; at most 512 images per call).  mgdt_cnx_block_supported: c in {32, 64, 96}, bf16, a tile decomposition with at most as many tiles per image as the chip has
- * compute units (every workgroup of a launch is resident at once; larger batches run as several launches of whole images). */
+ * compute units (every workgroup of a launch is resident at once; larger batches run as several launches of whole images).
+ * tail_w / tail_b / tail_act (NULL / NULL / 0 for none): a 1x1 Conv + BN + act applied to the block's output inside the launch - the IFM's closing
+ * Conv (nn/modules/block.py:336-338) - packed with mgdt_conv_pack(c, cout, 1, bf16) over input channels in the accumulator order of
+ * mgdt_conv1x1_inject_conv_fwd's note (j < c / 32); y then has cout <= c channels and the block's own output is never stored. */
 int mgdt_cnx_block_supported(int n, int h, int w, int c, int dtype);
 size_t mgdt_cnx_block_workspace_bytes(int n, int h, int w, int c);
 int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, const float* dw_b, const float* ln_w, const float* ln_b, float eps, const void* packed,
-                       const float* gamma, const float* beta, void* ws, size_t ws_bytes, const mgdt_view* y, int dtype, mgdt_stream s);
+                       const float* gamma, const float* beta, const void* tail_w, const float* tail_b, int tail_act, void* ws, size_t ws_bytes,
+                       const mgdt_view* y, int dtype, mgdt_stream s);
 
 /* ---- layers 0 and 1 of every YOLOv8 graph (Conv 3->16 k3 s2, Conv 16->32 k3 s2, both + BN + SiLU; models/v8/*.yaml rows 0-1) in one
  * launch, bf16 path: the image patch is staged in LDS with 16-byte row loads, layer 0 runs on MFMA out of LDS, its map never leaves the

@@ -65,7 +65,7 @@ PROTOTYPES = {
     'mgdt_cnx_mlp_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, VP, _i, _vp]),
     'mgdt_cnx_block_supported': (_i, [_i, _i, _i, _i, _i]),
     'mgdt_cnx_block_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'mgdt_cnx_block_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, VP, _i, _vp]),
+    'mgdt_cnx_block_fwd': (_i, [VP, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, VP, _i, _vp]),
     'mgdt_pw_chain_packed_bytes': (_sz, [_i, _i]),
     'mgdt_pw_chain_pack': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     'mgdt_pw_chain3_fwd': (_i, [VP, _vp, _i, _i, VP, _i, _vp]),

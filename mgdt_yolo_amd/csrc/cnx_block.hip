@@ -38,6 +38,7 @@ struct CnxArgs {
   int N, H, W, C, TH, TW, RH, RW, SEGS, tiles_x, tiles, n0;
   FastDiv fd_rw, fd_tw;
   GeluCoef gelu;
+  const char* w3; const float* b3; int act3, C3;         // TAIL: a 1x1 Conv + BN + act on the block's output (IFM's closing conv), panel with K in accumulator order
   unsigned long long* dbg;
 };
 
@@ -59,7 +60,7 @@ static inline CnxLds cnx_lds(int c, int th, int tw) {
   return l;
 }
 
-template <int KC1>
+template <int KC1, bool TAIL>
 __global__ __launch_bounds__(CNX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void cnx_block_kernel(const CnxArgs a, const CnxLds L) {
   constexpr int C = 32 * KC1, Q = C / 4, PCS = C / 8, HD = 4 * C;
   constexpr int NB1 = 8 * KC1, KC2 = 4 * KC1, NB2 = 2 * KC1, BPC = 2;
@@ -301,6 +302,10 @@ __global__ __launch_bounds__(CNX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     asm volatile("" ::"v"(prev));                           // the returned value is waited for: the exchange has been performed
   }
   __syncthreads();
+  if (TAIL) {                                               // the per-wave sums in T have been read: the closing conv's panel goes there
+    constexpr int W3V = (NB2 / 2) * NB2 * 64;               // 16-byte words: KC3 = NB2 / 2 chunks x NB2 cout blocks
+    for (int i = tid; i < W3V; i += CNX_THREADS) ((uint4*)Tb)[i] = ((const uint4*)a.w3)[i];
+  }
   if (tid == 0) {
     // arrival counter + generation: the last of the image's `tiles` workgroups resets the counter and opens the next generation; the others
     // wait for the generation they read BEFORE arriving to change.  The pair is back in its rest state (counter 0) when the kernel ends,
@@ -366,13 +371,42 @@ __global__ __launch_bounds__(CNX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
       for (int nb = 0; nb < NB2; ++nb) acc2[nb] = mma(*(const bf16x8*)(w2lane + (j * NB2 + nb) * 1024), B2, acc2[nb]);
     }
+    if (!TAIL) {
 #pragma unroll
-    for (int nb = 0; nb < NB2; ++nb) {
-      const int cob = (nb * 16 + 4 * g) * 2;
-      const int dead = cob >= C * 2 ? MGDT_OOB : 0;
-      const bf16x4 rb = __builtin_bit_cast(bf16x4, resr[nb]);
-      const f32x4 v = acc2[nb] + f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
-      bstore4<bf16>(yrs, (uint32_t)(yo | dead) + cob, v);
+      for (int nb = 0; nb < NB2; ++nb) {
+        const int cob = (nb * 16 + 4 * g) * 2;
+        const int dead = cob >= C * 2 ? MGDT_OOB : 0;
+        const bf16x4 rb = __builtin_bit_cast(bf16x4, resr[nb]);
+        const f32x4 v = acc2[nb] + f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+        bstore4<bf16>(yrs, (uint32_t)(yo | dead) + cob, v);
+      }
+    } else {
+      // the block's output (rounded to bf16 as the stored map would be) is the next conv's B operand: chunk j3 = output blocks 2*j3, 2*j3 + 1
+      constexpr int KC3 = NB2 / 2, NB3 = NB2;
+      const char* const w3lane = Tb + lane * 16;
+      f32x4 acc3[NB3];
+#pragma unroll
+      for (int nb = 0; nb < NB3; ++nb) acc3[nb] = *(const f32x4*)(a.b3 + nb * 16 + 4 * g);
+#pragma unroll
+      for (int j3 = 0; j3 < KC3; ++j3) {
+        bf16x8 B3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x4 rb = __builtin_bit_cast(bf16x4, resr[2 * j3 + h]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) B3[h * 4 + i] = (bf16)(acc2[2 * j3 + h][i] + (float)rb[i]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB3; ++nb) acc3[nb] = mma(*(const bf16x8*)(w3lane + (j3 * NB3 + nb) * 1024), B3, acc3[nb]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB3; ++nb) {
+        const int co = nb * 16 + 4 * g;
+        f32x4 v = acc3[nb];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a.act3 == MGDT_ACT_SILU ? v[i] * fast_sigmoid(v[i]) : act_apply(v[i], a.act3);
+        bstore4<bf16>(yrs, co < a.C3 ? (uint32_t)yo + (uint32_t)(co * 2) : (uint32_t)MGDT_OOB, v);
+      }
     }
   }
   if (dbg) { TT[6] = wall_clock64(); for (int i = 0; i < 7; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = TT[i]; }
@@ -413,11 +447,11 @@ extern "C" size_t mgdt_cnx_block_workspace_bytes(int n, int h, int w, int c) {
   return 4096 + (size_t)n * cdiv(h, th) * cdiv(w, tw) * 4 * c * sizeof(float);
 }
 
-template <int KC1>
+template <int KC1, bool TAIL>
 static int cnx_launch(CnxArgs& a, const CnxLds& L, hipStream_t st) {
   static std::atomic<bool> attr{false};
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)cnx_block_kernel<KC1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)cnx_block_kernel<KC1, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "cnx_block: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
@@ -434,17 +468,20 @@ static int cnx_launch(CnxArgs& a, const CnxLds& L, hipStream_t st) {
   const int N = a.N;
   for (int n0 = 0; n0 < N; n0 += per_launch) {
     a.n0 = n0;
-    cnx_block_kernel<KC1><<<std::min(per_launch, N - n0) * a.tiles, CNX_THREADS, L.total, st>>>(a, L);
+    cnx_block_kernel<KC1, TAIL><<<std::min(per_launch, N - n0) * a.tiles, CNX_THREADS, L.total, st>>>(a, L);
   }
   return MGDT_OK;
 }
 
 extern "C" int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, const float* dw_b, const float* ln_w, const float* ln_b, float eps, const void* packed,
-                                  const float* gamma, const float* beta, void* ws, size_t ws_bytes, const mgdt_view* y, int dtype, mgdt_stream s) {
+                                  const float* gamma, const float* beta, const void* tail_w, const float* tail_b, int tail_act, void* ws, size_t ws_bytes,
+                                  const mgdt_view* y, int dtype, mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y) || !dw_w49c || !dw_b || !ln_w || !ln_b || !packed || !gamma || !beta || !ws) MGDT_FAIL(MGDT_BAD_ARG, "cnx_block: null/empty argument");
   const int kc1 = cnx_kc1(x->c, dtype);
   if (!kc1 || !mgdt_cnx_block_supported(x->n, x->h, x->w, x->c, dtype)) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: n=%d %dx%d c=%d dtype=%d not covered", x->n, x->h, x->w, x->c, dtype);
-  if (y->n != x->n || y->h != x->h || y->w != x->w || y->c != x->c) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: x and y must have one shape");
+  const bool tail = tail_w != nullptr;
+  if (y->n != x->n || y->h != x->h || y->w != x->w || (!tail && y->c != x->c) || (tail && (!tail_b || y->c > x->c || y->c % 4)))
+    MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: x and y must have one shape (with a closing conv: its output channels <= c, %% 4)");
   if (x->n > 512) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: at most 512 images per call");
   if (ws_bytes < mgdt_cnx_block_workspace_bytes(x->n, x->h, x->w, x->c) || (uintptr_t)ws % 16) MGDT_FAIL(MGDT_WORKSPACE, "cnx_block: workspace too small / unaligned");
   CnxArgs a;
@@ -462,6 +499,7 @@ extern "C" int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, cons
   a.y = (char*)yp;
   a.dww = dw_w49c; a.dwb = dw_b; a.lnw = ln_w; a.lnb = ln_b; a.eps = eps; a.packed = (const char*)packed; a.gamma = gamma; a.beta = beta;
   a.sync = (unsigned*)ws; a.part = (float*)((char*)ws + 4096);
+  a.w3 = (const char*)tail_w; a.b3 = tail_b; a.act3 = tail_act; a.C3 = y->c;
   a.N = x->n; a.H = x->h; a.W = x->w; a.C = x->c;
   if (!cnx_pick_tile(a.H, a.W, a.C, &a.TH, &a.TW)) MGDT_FAIL(MGDT_BAD_SHAPE, "cnx_block: no tile");
   a.SEGS = cdiv(a.TW, CNX_PX); a.RW = a.SEGS * CNX_PX + 6; a.RH = a.TH + 6;
@@ -476,9 +514,9 @@ extern "C" int mgdt_cnx_block_fwd(const mgdt_view* x, const float* dw_w49c, cons
   hipStream_t st = (hipStream_t)s;
   int rc;
   switch (kc1) {
-    case 1: rc = cnx_launch<1>(a, L, st); break;
-    case 2: rc = cnx_launch<2>(a, L, st); break;
-    default: rc = cnx_launch<3>(a, L, st); break;
+    case 1: rc = tail ? cnx_launch<1, true>(a, L, st) : cnx_launch<1, false>(a, L, st); break;
+    case 2: rc = tail ? cnx_launch<2, true>(a, L, st) : cnx_launch<2, false>(a, L, st); break;
+    default: rc = tail ? cnx_launch<3, true>(a, L, st) : cnx_launch<3, false>(a, L, st); break;
   }
   if (rc != MGDT_OK) return rc;
   MGDT_CHECK_LAUNCH("cnx_block_fwd");

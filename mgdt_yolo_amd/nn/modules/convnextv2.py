@@ -30,6 +30,23 @@ class ConvNeXtV2_Block(HipModule):
         self.pwconv2 = nn.Linear(4 * dim, dim)
         self.drop_path = nn.Identity()
 
+    @staticmethod
+    def _tail_panel(conv, dim, dt):
+        """PackedConv of a plain 1x1 Conv+BN+act over this block's `dim` channels with its input channels in accumulator order, or None"""
+        from .conv import Conv, act_code
+        if (not ops.FUSED_CNX_TAIL or not isinstance(conv, Conv) or not hasattr(conv, 'bn') or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1)
+                or conv.conv.groups != 1 or conv.conv.bias is not None or conv.conv.in_channels != dim or conv.conv.out_channels > dim or conv.conv.out_channels % 4
+                or conv.__dict__.get('_q8') or ops.Q8_CALIB is not None or conv._forward_hooks):
+            return None
+        try:
+            act_code(conv.act)
+        except RuntimeError:
+            return None
+        tens = [conv.conv.weight, conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var]
+        return conv._cached(('acc_order', dt), tens, lambda: ops.PackedConv(
+            conv.conv.weight.detach()[:, ops.acc_order_index(dim, conv.conv.weight.device)], None,
+            (conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var, conv.bn.eps), 1, dt))
+
     def backward(self, g):
         x, u, t1, y1, t2, t3, S, pw1, pw2, dw, gb = self._ctx.pop()
         dim = self.dwconv.in_channels
@@ -69,7 +86,9 @@ class ConvNeXtV2_Block(HipModule):
         self._save_ctx((x, u, t1, y1, t2, t3, S, pw1_raw, pw2, dw, gb))
         return out
 
-    def forward(self, x):
+    def forward(self, x, tail=None):
+        """`tail` (IFM, eval only): the 1x1 Conv+BN+act module that consumes this block's output and nothing else - it then runs inside the block's
+        launch; the return value is (conv output, True) when that happened, else this block's output as usual."""
         dt = x.dtype
         dim = self.dwconv.in_channels
         dw = self._cached('dw', [self.dwconv.weight],
@@ -90,6 +109,11 @@ class ConvNeXtV2_Block(HipModule):
                                lambda: ops.PackedCnxMlp(self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias, dt))
             vec = self._cached('dwln', [self.dwconv.bias, self.norm.weight, self.norm.bias],
                                lambda: tuple(t.detach().float().contiguous() for t in (self.dwconv.bias, self.norm.weight, self.norm.bias)))
+            if tail is not None:
+                pk3 = self._tail_panel(tail, dim, dt)
+                if pk3 is not None:
+                    from .conv import act_code
+                    return ops.cnx_block(x, dw, vec[0], vec[1], vec[2], self.norm.eps, mlp, gb[0], gb[1], tail=pk3, tail_act=act_code(tail.act)), True
             return ops.cnx_block(x, dw, vec[0], vec[1], vec[2], self.norm.eps, mlp, gb[0], gb[1])
         t = ops.dwconv7_ln(x, dw, self.dwconv.bias.detach().float(), self.norm.weight.detach().float(), self.norm.bias.detach().float(),
                            self.norm.eps)

@@ -515,6 +515,7 @@ def cnx_mlp(t, res, pk, gamma, beta, out=None):
 
 
 FUSED_CNX_BLOCK = True  # tests flip this to compare against dwconv7_ln + the two-pass MLP
+FUSED_CNX_TAIL = True   # ... and the IFM's closing 1x1 conv inside the last block's launch vs a launch of its own
 _CNX_WS = {}            # (device, shape) -> zero-initialised workspace of mgdt_cnx_block_fwd (its barrier words live across calls)
 
 
@@ -523,10 +524,12 @@ def cnx_block_supported(x, dtype):
     return bool(FUSED_CNX_BLOCK and x.dtype == dtype and is_nhwc(x) and L.lib().mgdt_cnx_block_supported(b, h, w, c, dtype_code(dtype)))
 
 
-def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None):
-    """out = x + pwconv2(GRN(gelu(pwconv1(LayerNorm(dwconv7x7(x)))))) in one launch (mgdt_cnx_block_fwd)."""
+def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None, tail=None, tail_act=0):
+    """out = x + pwconv2(GRN(gelu(pwconv1(LayerNorm(dwconv7x7(x)))))) in one launch (mgdt_cnx_block_fwd); `tail`: PackedConv (input channels in
+    `acc_order_index` order) of a 1x1 Conv+BN+act applied to that result inside the launch - `out` then has the conv's channels."""
     b, c, h, w = x.shape
-    out = like(x) if out is None else out
+    if out is None:
+        out = like(x) if tail is None else new_act(b, tail.cout, h, w, x.dtype, x.device)
     if out.data_ptr() == x.data_ptr():
         raise RuntimeError('cnx_block: the output may not alias the input (tiles read their neighbours\' halo)')
     nbytes = L.lib().mgdt_cnx_block_workspace_bytes(b, h, w, c)
@@ -534,12 +537,12 @@ def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None):
     ws = _CNX_WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('cnx_block: run the model once before capturing it into a graph (the kernel\'s arrival counters are allocated and zeroed on first use)')
+            raise RuntimeError('cnx_block: run the model once before capturing it into a graph (the kernel\'s barrier words are allocated and zeroed on first use)')
         ws = _CNX_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
     if _PROF is not None:
         _META['cnx_block_fwd'] = dict(shape=(b, c, h, w, c, 7, 1), flops=2.0 * b * h * w * c * (4 * c * 2 + 49), bytes=float(2 * b * h * w * c * x.element_size()))
-    _launch('cnx_block_fwd', 'mgdt_cnx_block_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), float(eps), ptr(pk.blob), ptr(gamma), ptr(beta), ptr(ws), nbytes,
-            vp(out), dtype_code(x.dtype), stream())
+    _launch('cnx_block_fwd', 'mgdt_cnx_block_fwd', vp(x), ptr(dw_w49c), ptr(dw_b), ptr(ln_w), ptr(ln_b), float(eps), ptr(pk.blob), ptr(gamma), ptr(beta),
+            None if tail is None else ptr(tail.w), None if tail is None else ptr(tail.bias), int(tail_act), ptr(ws), nbytes, vp(out), dtype_code(x.dtype), stream())
     return out
 
 

@@ -131,6 +131,38 @@ def test_convnext_block_single_launch_matches_the_launch_chain(b, dim, hw):
     assert e_chain < 2e-2 * scale and e32 < 3e-2 * scale
 
 
+@pytest.mark.parametrize('b,inc,hw', [(32, 480, (40, 40)), (2, 48, (10, 6)), (3, 64, (23, 17))])
+def test_ifm_closing_conv_inside_the_last_block_launch(b, inc, hw):
+    """IFM (nn/modules/block.py:331-342) in bf16: Conv 1x1, three one-launch ConvNeXtV2 blocks, and the closing Conv 1x1 + BN + SiLU evaluated
+    inside the LAST block's launch (its output goes from pwconv2's accumulators + residual, rounded to bf16 as the stored map would be, into
+    the closing conv's MFMA).  Against the same module with ops.FUSED_CNX_TAIL off (closing conv as its own launch): same roundings, another
+    summation order over the 96 input channels -> bf16 resolution (1.5e-2 of the largest output)."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import IFM
+    m = seed_state_dict_(IFM(inc, [64, 32]), 5).eval().to(DEV)
+    m.apply(lambda t: setattr(t, '_cdtype', torch.bfloat16) if hasattr(t, 'out_dtype') else None)
+    x = torch.randn(b, inc, *hw, generator=torch.Generator().manual_seed(2)).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    names = []
+    orig = ops._launch
+    with torch.no_grad():
+        m(x)
+        ops._launch = lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1]
+        try:
+            y1 = m(x).float()
+        finally:
+            ops._launch = orig
+        ops.FUSED_CNX_TAIL = False
+        try:
+            y0 = m(x).float()
+        finally:
+            ops.FUSED_CNX_TAIL = True
+    assert names == ['conv2d_fwd', 'cnx_block_fwd', 'cnx_block_fwd', 'cnx_block_fwd'], names
+    scale = y0.abs().max().item()
+    err = (y1 - y0).abs().max().item()
+    print(f'IFM {b}x{inc}x{hw}: closing conv in the block launch vs its own launch: {err / scale:.2e} of {scale:.2f}')
+    assert err < 1.5e-2 * scale
+
+
 def test_convnext_block_barrier_words_survive_a_change_of_shape():
     """The per-image barrier of mgdt_cnx_block_fwd (arrival counter + generation in the workspace) must be at rest after every call whatever
     the tile count was: one workspace shared by a 1-tile-per-image shape (called an odd number of times) and a 2-tile-per-image shape.  (The
