@@ -180,7 +180,8 @@ def roofline_of(prof_rows, reps, step_ms, graph, args):
         ach = bytes_l / avg_s / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4)}
     kern = {'conv2d_fp8_fwd': 'conv_igemm_kernel<.., Q8> (e4m3 MFMA)', 'conv2d_fwd': 'conv_igemm_kernel (+ conv3x3_lds_kernel for the 64->96 Detect-branch 3x3)', 'conv2d_direct_fwd': 'conv_stem_kernel', 'cnx_mlp_fwd': 'cnx_mlp_kernel<STATS> + cnx_mlp_kernel<APPLY>',
-            'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel', 'csp_block_fwd': 'csp_block_kernel'}.get(name, name)
+            'pw_chain3_fwd': 'pw_chain3_kernel', 'conv1x1_inject_fwd': 'conv1x1_inject_kernel', 'csp_block_fwd': 'csp_block_kernel',
+            'cnx_block_fwd': 'cnx_block_kernel', 'conv1x1_inject_conv_fwd': 'conv1x1_inject_conv_kernel'}.get(name, name)
     traffic, tsrc, tat, tstale = None, None, None, None
     # the launches the PMC figure was averaged over, as a fingerprint: op name + every (shape, launches per step) of the family + the step's
     # launch count.  tools/pmc_summary.py stores the fingerprint of the run it measured; a different one here means the kernel set changed
@@ -373,6 +374,15 @@ def main():
                            'input': x_desc, 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)',
                            'timed_region_s': round(elapsed, 3)},
                 'roofline': roof}
+        # whole-step fractions against SURVEY 8(d)'s layer-level algorithmic work per image (each top-level layer reads its inputs and writes
+        # its output once, weights amortised; 2*MAC over every conv / linear): the distance of the WHOLE step - not of one kernel - from the chip
+        per_img = {('mspa_c2f_gd_yolov8', 'n', 640): (22.04e6, 5.278e9), ('yolov8', 'n', 640): (23.21e6, 7.479e9)}.get((args.model, args.scale, args.imgsz))
+        if per_img is not None and args.mode == 'infer' and roof is not None:
+            esz = 4 if args.dtype == 'f32' else 2
+            by, fl = per_img[0] * esz * args.batch, per_img[1] * args.batch
+            roof['step_hbm_frac'] = round(by / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+            roof['step_mfma_frac'] = round(fl / (ms_step * 1e-3) / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12), 4)
+            roof['step_algorithmic'] = {'bytes_per_step': round(by), 'flops_per_step': round(fl), 'source': 'SURVEY.md 8(d): 22.04 M elements and 5.278 GFLOP per 640x640 image (layer granularity)'}
         if not args.no_cpu_baseline and world == 1 and args.mode == 'infer':
             line['cpu_baseline'] = cpu_baseline(cfg, model, args)
         else:
