@@ -159,11 +159,22 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
   char* w2l = smem + (size_t)KC * NB * 1024;               // [KC2][NB2][64][16 B]
   T* sg = (T*)(w2l + (size_t)KC2 * NB2 * 1024);
   T* sf = sg + (size_t)a.PH * a.PW * CS;
+  // GCONV: the two source patches are kept TRANSPOSED, as MFMA A fragments over K = source pixel (<= 64 = 2 chunks): frag(nb, kc)[lane (r, g)][e] =
+  // map[source pixel kc*32 + 8g + e][channel nb*16 + r].  The bilinear interpolation of all 256 channels of 16 output pixels is then two
+  // MFMAs per 16-channel block and map (B = the lane's pixel's four tap weights scattered over its 64 source-pixel slots) instead of ~100
+  // VALU instructions per block: the tail was VALU-bound (h_sigmoid + four-tap lerps in fp32 for 2 x 256 channels per pixel).  h_sigmoid is
+  // applied once per source pixel while the patch is built (the gate is then rounded to bf16 once more: <= 2^-9 relative on the gate).
+  char* hgT = (char*)sg;                                   // [NB][2][64 lanes][16 B]
+  char* gfT = hgT + (size_t)NB * 2 * 1024;
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   for (int i = tid; i < KC * NB * 64; i += THREADS) ((uint4*)wl)[i] = ((const uint4*)a.wpk)[i];
   for (int i = tid; i < KC2 * NB2 * 64; i += THREADS) ((uint4*)w2l)[i] = ((const uint4*)A.w2)[i];
+  if (GCONV) {
+    for (int i = tid; i < NB * 2 * 2 * 64; i += THREADS) ((uint4*)hgT)[i] = make_uint4(0u, 0u, 0u, 0u);     // unused source slots must stay finite (x 0 weights)
+  }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)A.y2, 0, A.y2_bytes, 0x00020000);
   const char* const wlane = wl + lane * 16;
@@ -216,11 +227,14 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
         for (int t = 0; t < GB; ++t) {
           const int nbg = wave * GB + t;                    // uniform
           const f32x4 o = mma(Ag[t], Bg, bg[t]);
-          bf16x4 ob;
+          const bool gate = nbg < NB;                        // uniform
+          char* base = (gate ? hgT : gfT) + ((size_t)((nbg % NB) * 2 + (p >> 5)) * 64 + ((p & 31) >> 3) * 16 + 4 * g) * 16 + (p & 7) * 2;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ob[i] = (bf16)o[i];   // the stored (rounded) global maps
-          T* dst = (nbg < NB ? sg : sf) + (size_t)p * CS + (nbg % NB) * 16 + 4 * g;
-          if (v_) *(bf16x4*)dst = ob;
+          for (int i = 0; i < 4; ++i) {
+            float v = (float)(bf16)o[i];                     // the stored (rounded) global map value
+            if (gate) v = fminf(fmaxf(fmaf(v, 1.f / 6.f, 0.5f), 0.f), 1.f);      // h_sigmoid (block.py:344-350) before the interpolation (block.py:393)
+            if (v_) *(bf16*)(base + i * 16) = (bf16)v;       // lane slot (r = 4g + i, g' = source pixel / 8), element = source pixel % 8
+          }
         }
       }
     } else {
@@ -261,11 +275,39 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
     f32x4 acc2[NB2];
 #pragma unroll
     for (int nb = 0; nb < NB2; ++nb) acc2[nb] = *(const f32x4*)(A.bias2 + nb * 16 + 4 * g);
+    // GCONV: this lane's pixel as an interpolation B operand: its four tap weights at their source-pixel slots (coinciding taps add up), zeros elsewhere
+    frag WB[2];
+    if (GCONV) {
+      const int s00 = (y0 - py0) * pw + (x0 - px0), s01 = (y0 - py0) * pw + (x1 - px0), s10 = (y1 - py0) * pw + (x0 - px0), s11 = (y1 - py0) * pw + (x1 - px0);
+      const float w00 = (1.f - wy1) * (1.f - wx1), w01 = (1.f - wy1) * wx1, w10 = wy1 * (1.f - wx1), w11 = wy1 * wx1;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int sidx = kc * 32 + 8 * g + e;
+          const float w = (sidx == s00 ? w00 : 0.f) + (sidx == s01 ? w01 : 0.f) + (sidx == s10 ? w10 : 0.f) + (sidx == s11 ? w11 : 0.f);
+          WB[kc][e] = (bf16)w;
+        }
+    }
+    const char* const hglane = hgT + lane * 16;
+    const char* const gflane = gfT + lane * 16;
 #pragma unroll
     for (int j = 0; j < KC2; ++j) {
       frag B2;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        if constexpr (GCONV) {
+          const int nb = 2 * j + h;
+          f32x4 sig = f32x4{0.f, 0.f, 0.f, 0.f}, feat = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            sig = mma(*(const frag*)(hglane + (nb * 2 + kc) * 1024), WB[kc], sig);
+            feat = mma(*(const frag*)(gflane + (nb * 2 + kc) * 1024), WB[kc], feat);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) B2[h * 4 + i] = (T)((float)(T)acc[nb][i] * sig[i] + feat[i]);
+          continue;
+        }
         const int c = (2 * j + h) * 16;
         const f32x4 sig = (hs(ld(sg, o00 + c)) * (1.f - wx1) + hs(ld(sg, o01 + c)) * wx1) * (1.f - wy1) +
                           (hs(ld(sg, o10 + c)) * (1.f - wx1) + hs(ld(sg, o11 + c)) * wx1) * wy1;
@@ -378,7 +420,8 @@ static void inj_patch_th(int H, int W, int Hg, int Wg, int TH, int* PH, int* PW)
   *PH = ph; *PW = pw;
 }
 static size_t inj2_lds(int kc, int nb, int nb2, int PH, int PW) {
-  return (size_t)kc * nb * 1024 + (size_t)(nb / 2) * nb2 * 1024 + (size_t)2 * PH * PW * (nb * 16 + INJ_CPAD) * 2;
+  // patches: [pixel][channel] rows (maps computed by the caller) or, GCONV, 2 maps x nb blocks x 2 K chunks x 1 KiB fragments - never more than the rows
+  return (size_t)kc * nb * 1024 + (size_t)(nb / 2) * nb2 * 1024 + std::max((size_t)2 * PH * PW * (nb * 16 + INJ_CPAD) * 2, (size_t)2 * nb * 2 * 1024);
 }
 
 /* 1 when mgdt_conv1x1_inject_conv_fwd covers the shapes: bf16, cin <= 128 (% 8), injection width 256, second conv 256 -> cout2 <= 64 (% 16) */
@@ -386,7 +429,7 @@ extern "C" int mgdt_conv1x1_inject_conv_supported(int cin, int cmid, int cout2, 
   if (dtype != MGDT_BF16 || cin % 8 || cin > 128 || cmid != 256 || cout2 % 16 || cout2 < 16 || cout2 > 64 || h < hg || w < wg || hg < 1 || wg < 1) return 0;
   int PH, PW;
   inj_patch_th(h, w, hg, wg, INJ2_TH, &PH, &PW);
-  return inj2_lds(inj_kc(cin), cmid / 16, cout2 / 16, PH, PW) <= 156 * 1024;
+  return PH * PW <= 64 && inj2_lds(inj_kc(cin), cmid / 16, cout2 / 16, PH, PW) <= 156 * 1024;      // source patch within the 64 K slots of the MFMA interpolation
 }
 
 template <int KC, int NB2, bool GCONV>

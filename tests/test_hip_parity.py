@@ -355,7 +355,11 @@ def test_injection_plus_c2f_cv1_single_launch_matches_two_launches(b, hw, ghw):
             y01_g = inj.forward_into_conv([x_l, x_g], c2f.cv1)
         finally:
             ops.FUSED_INJECT_GCONV = True
-        assert (y01_f is None) == (y01_g is None) and (y01_f is None or torch.equal(y01_f, y01_g))
+        # (the in-launch form interpolates on the MFMA with bf16 tap weights and a bf16-rounded h_sigmoid gate: bf16-resolution agreement)
+        assert (y01_f is None) == (y01_g is None)
+        if y01_f is not None:
+            dg = (y01_f.float() - y01_g.float()).abs().max().item()
+            assert dg < 1.5e-2 * y01_g.float().abs().max().item(), dg
         y01_t = c2f.cv1(inj([x_l, x_g])).float()
         if ghw == hw:            # no up-sampling: the source patches of an 8 x 16 tile do not fit LDS next to both panels -> the two-launch form by itself
             assert y01_f is None
