@@ -194,35 +194,60 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
   }
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(GCONV ? A.gx : a.x), 0, GCONV ? A.gx_bytes : 0u, 0x00020000);
   const int npatch = a.N * a.tiles_x * a.tiles_y;
-#pragma unroll 1
-  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+  // Everything a patch reads from HBM - this lane's x fragments and (GCONV) the source pixels of the global convs - is requested ONE PATCH
+  // AHEAD, right after the LDS patch of the current one is built: with one 8-wave workgroup per CU nothing else hides that round trip.
+  constexpr int NG = 4;                                    // 16-pixel groups of a source patch (host: PH * PW <= 64)
+  auto geom = [&](int patch, int& n, int& ty, int& tx, int& py0, int& px0, int& ph, int& pw) __attribute__((always_inline)) {
     int b = patch;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y, n = b / a.tiles_y;
-    const int oy = ty * TH + wave, ox = tx * INJ_TW + r;
-    const bool pv = oy < a.H && ox < a.W;
-    const int xo = pv ? n * a.xsn + oy * a.xsh + ox * a.xsw : MGDT_OOB;
-    frag P[KC];
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const int cb = (kc * 4 + g) * 16;
-      P[kc] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, (cb < a.Cin * SZ) ? (uint32_t)(xo + cb) : (uint32_t)MGDT_OOB, 0, 0));
-    }
-    int py0, py1, px0, px1, t0, t1; float tl;
+    tx = b % a.tiles_x; b /= a.tiles_x;
+    ty = b % a.tiles_y; n = b / a.tiles_y;
+    int py1, px1, t0, t1; float tl;
     inj_lerp(ty * TH, a.Hg, a.H, py0, t1, tl);
     inj_lerp(min(ty * TH + TH - 1, a.H - 1), a.Hg, a.H, t0, py1, tl);
     inj_lerp(tx * INJ_TW, a.Wg, a.W, px0, t1, tl);
     inj_lerp(min(tx * INJ_TW + INJ_TW - 1, a.W - 1), a.Wg, a.W, t0, px1, tl);
-    const int ph = py1 - py0 + 1, pw = px1 - px0 + 1;
+    ph = py1 - py0 + 1; pw = px1 - px0 + 1;
+  };
+  auto request = [&](int patch, frag(&Pq)[KC], frag(&Bq)[NG]) __attribute__((always_inline)) {
+    int n, ty, tx, py0, px0, ph, pw;
+    const bool live = patch < npatch;
+    geom(live ? patch : 0, n, ty, tx, py0, px0, ph, pw);
+    const int oy = ty * TH + wave, ox = tx * INJ_TW + r;
+    const int xo = (live && oy < a.H && ox < a.W) ? n * a.xsn + oy * a.xsh + ox * a.xsw : MGDT_OOB;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int cb = (kc * 4 + g) * 16;
+      Pq[kc] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(xrs, (cb < a.Cin * SZ) ? (uint32_t)(xo + cb) : (uint32_t)MGDT_OOB, 0, 0));
+    }
+    if (GCONV) {
+      const int npx = ph * pw;
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        const int p = grp * 16 + r;
+        const bool v_ = live && p < npx;
+        const int sy = (v_ ? p : 0) / pw, sx = (v_ ? p : 0) - sy * pw;
+        const uint32_t go = v_ ? (uint32_t)(n * A.gxsn + (py0 + sy) * A.gxsh + (px0 + sx) * A.gxsw + g * 16) : (uint32_t)MGDT_OOB;
+        Bq[grp] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(grs, go, 0, 0));      // 32 input channels = one K chunk
+      }
+    }
+  };
+  frag P[KC], Pn[KC], Bgc[NG], Bgn[NG];
+  request((int)blockIdx.x, P, Bgc);
+#pragma unroll 1
+  for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+    int n, ty, tx, py0, px0, ph, pw;
+    geom(patch, n, ty, tx, py0, px0, ph, pw);
+    const int oy = ty * TH + wave, ox = tx * INJ_TW + r;
+    const bool pv = oy < a.H && ox < a.W;
     __syncthreads();                                       // the previous patch's tail is done with the LDS maps
     if (GCONV) {
       const int npx = ph * pw;
-      for (int grp = 0; grp * 16 < npx; ++grp) {
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp * 16 >= npx) break;                          // uniform
         const int p = grp * 16 + r;
         const bool v_ = p < npx;
-        const int sy = (v_ ? p : 0) / pw, sx = (v_ ? p : 0) - sy * pw;
-        const uint32_t go = v_ ? (uint32_t)(n * A.gxsn + (py0 + sy) * A.gxsh + (px0 + sx) * A.gxsw + g * 16) : (uint32_t)MGDT_OOB;
-        const frag Bg = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(grs, go, 0, 0));      // 32 input channels = one K chunk
+        const frag Bg = Bgc[grp];
 #pragma unroll
         for (int t = 0; t < GB; ++t) {
           const int nbg = wave * GB + t;                    // uniform
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
         *(uint4*)((char*)sf + ((size_t)p * CS + v * 8) * SZ) = vf;
       }
     }
+    request(patch + (int)gridDim.x, Pn, Bgn);              // the next patch's HBM reads fly under this patch's GEMMs and tail
     __syncthreads();
     f32x4 acc[NB];
 #pragma unroll
@@ -328,6 +354,10 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
       for (int i = 0; i < 4; ++i) v[i] = A.act2 == MGDT_ACT_SILU ? v[i] * fast_sigmoid(v[i]) : act_apply(v[i], A.act2);
       bstore4<T>(yrs, c < A.C2 ? (uint32_t)yo + (uint32_t)(c * SZ) : (uint32_t)MGDT_OOB, v);
     }
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) P[kc] = Pn[kc];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) Bgc[grp] = Bgn[grp];
   }
 }
 
