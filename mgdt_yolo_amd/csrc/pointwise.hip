@@ -616,12 +616,111 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x,
   }
 }
 
+// Separable form in TWO phases: three chained MaxPool2d(5, 1, 2) with -inf padding are the max over the 5x5, 9x9 and 13x13 windows clipped to the map
+// (max is associative and exact, so y1, y2, y3 are bit-identical to the chained pools).  Phase 1: per pixel the running maxima over 5 / 9 / 13
+// columns of its row; phase 2: the maxima over 5 / 9 / 13 rows of those - two barriers instead of the nine of the chained form (the kernel is
+// a latency chain: one small workgroup per (image, channel group), everything in LDS, in the storage type).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y1, long s1n, long s1h, long s1w,
+                                                         T* __restrict__ y2, long s2n, long s2h, long s2w, T* __restrict__ y3, long s3n, long s3h, long s3w, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char sm3[];
+  const int n = blockIdx.x, c0 = blockIdx.y * V, WP = W + 12, HP = H + 12;
+  T* X = (T*)sm3;                                           // [H][WP][V]: the rows of the map with a 6-column -inf halo
+  T* R = X + (size_t)H * WP * V;                            // [3][HP][W][V]: row maxima (5, 9, 13 wide) with a 6-row -inf halo
+  float ninf[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) ninf[k] = -INFINITY;
+  for (int i = threadIdx.x; i < H * WP; i += 256) {
+    const int h = i / WP, wp = i - h * WP, w = wp - 6;
+    float v[V];
+    if ((unsigned)w < (unsigned)W) ldv<T, V>(x + n * xsn + h * xsh + w * xsw + c0, v);
+    else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = -INFINITY;
+    }
+    stv<T, V>(X + (size_t)i * V, v);
+  }
+  for (int i = threadIdx.x; i < 3 * 12 * W; i += 256) {    // halo rows of the three row-maximum planes
+    const int pl = i / (12 * W), rem = i - pl * 12 * W, hr = rem / W, w = rem - hr * W;
+    const int hp = hr < 6 ? hr : H + hr;                   // rows 0..5 and H+6..H+11
+    stv<T, V>(R + ((size_t)(pl * HP + hp) * W + w) * V, ninf);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    const int h = i / W, w = i - h * W;
+    const T* row = X + ((size_t)h * WP + w) * V;            // row[j] = column w - 6 + j
+    float t[13][V];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) ldv<T, V>(row + (size_t)j * V, t[j]);
+    float m5[V], m9[V], m13[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      m5[k] = fmaxf(fmaxf(fmaxf(t[4][k], t[5][k]), fmaxf(t[6][k], t[7][k])), t[8][k]);
+      m9[k] = fmaxf(fmaxf(m5[k], fmaxf(t[2][k], t[3][k])), fmaxf(t[9][k], t[10][k]));
+      m13[k] = fmaxf(fmaxf(m9[k], fmaxf(t[0][k], t[1][k])), fmaxf(t[11][k], t[12][k]));
+    }
+    stv<T, V>(R + ((size_t)(0 * HP + h + 6) * W + w) * V, m5);
+    stv<T, V>(R + ((size_t)(1 * HP + h + 6) * W + w) * V, m9);
+    stv<T, V>(R + ((size_t)(2 * HP + h + 6) * W + w) * V, m13);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    const int h = i / W, w = i - h * W;
+    float o[V], t[V];
+    // y1: 5 rows of the 5-wide maxima
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = -INFINITY;
+#pragma unroll
+    for (int j = 4; j <= 8; ++j) {
+      ldv<T, V>(R + ((size_t)(0 * HP + h + j) * W + w) * V, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = fmaxf(o[k], t[k]);
+    }
+    stv<T, V>(y1 + n * s1n + h * s1h + w * s1w + c0, o);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = -INFINITY;
+#pragma unroll
+    for (int j = 2; j <= 10; ++j) {
+      ldv<T, V>(R + ((size_t)(1 * HP + h + j) * W + w) * V, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = fmaxf(o[k], t[k]);
+    }
+    stv<T, V>(y2 + n * s2n + h * s2h + w * s2w + c0, o);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = -INFINITY;
+#pragma unroll
+    for (int j = 0; j <= 12; ++j) {
+      ldv<T, V>(R + ((size_t)(2 * HP + h + j) * W + w) * V, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = fmaxf(o[k], t[k]);
+    }
+    stv<T, V>(y3 + n * s3n + h * s3h + w * s3w + c0, o);
+  }
+}
+
 extern "C" int mgdt_sppf_pool_fwd(const mgdt_view* x, const mgdt_view* y1, const mgdt_view* y2, const mgdt_view* y3, int dtype,
                                   mgdt_stream s) {
   if (!view_ok(x) || !view_ok(y1) || !view_ok(y2) || !view_ok(y3)) MGDT_FAIL(MGDT_BAD_ARG, "sppf_pool: null/empty view");
   for (const mgdt_view* v : {x, y1, y2, y3})
     if (!vec4_ok(v, dtype) || v->n != x->n || v->h != x->h || v->w != x->w || v->c != x->c)
       MGDT_FAIL(MGDT_BAD_SHAPE, "sppf_pool: views must be matching NHWC, c%%4==0");
+  {
+    // two-phase form: LDS = rows + three row-maximum planes in the storage type
+    static const bool old_form = getenv("MGDT_SPPF_CHAINED") != nullptr;      // experiment knob: the chained three-pass kernel
+    bool all8 = true;
+    for (const mgdt_view* v : {x, y1, y2, y3}) all8 = all8 && vecN_ok(v, dtype, 8);
+    const int V3 = (dtype == MGDT_BF16 && all8) ? 8 : 4;
+    const size_t lds3 = ((size_t)x->h * (x->w + 12) + (size_t)3 * (x->h + 12) * x->w) * V3 * dtype_size(dtype);
+    if (!old_form && lds3 <= 64 * 1024) {
+      dim3 grid3(x->n, x->c / V3);
+      MGDT_DISPATCH_TV(dtype, all8, {
+        sppf_pool3_kernel<T, V><<<grid3, 256, lds3, (hipStream_t)s>>>((const T*)x->p, x->sn, x->sh, x->sw, (T*)y1->p, y1->sn, y1->sh, y1->sw, (T*)y2->p, y2->sn, y2->sh, y2->sw,
+                                                                    (T*)y3->p, y3->sn, y3->sh, y3->sw, x->h, x->w);
+      });
+      MGDT_CHECK_LAUNCH("sppf_pool_fwd");
+      return MGDT_OK;
+    }
+  }
   const long pp = (long)(x->h + 4) * (x->w + 4);                                  // plane with its 2-pixel halo
   const int cg = (x->c % 8 == 0 && pp * 8 * 2 * 4 <= 64 * 1024) ? 8 : 4;          // channels per workgroup so the planes fit 64 KiB of LDS
   size_t lds = (size_t)pp * cg * 2 * sizeof(float);

@@ -59,7 +59,15 @@ class HipModule(nn.Module):
         when the site runs in bf16."""
         if ops.Q8_CALIB is not None:
             xe = x if x2 is None else x.float() + x2.float()
-            ops.Q8_CALIB[(self, key)] = max(ops.Q8_CALIB.get((self, key), 0.0), float(xe.abs().max()))
+            if ops.Q8_CALIB_PCT is None:
+                amax = float(xe.abs().max())
+            else:                                            # a high percentile of |input| instead of its maximum (outliers saturate at +-448)
+                flat = xe.detach().abs().float().reshape(-1)
+                if flat.numel() > (1 << 20):
+                    flat = flat[::flat.numel() // (1 << 20)]
+                k = min(flat.numel(), max(1, int(round(ops.Q8_CALIB_PCT / 100.0 * flat.numel()))))
+                amax = float(flat.kthvalue(k).values)
+            ops.Q8_CALIB[(self, key)] = max(ops.Q8_CALIB.get((self, key), 0.0), amax)
         q = self.__dict__.get('_q8')
         return None if q is None else q.get(key)
 

@@ -321,27 +321,29 @@ class BaseModel(nn.Module):
         return self.set_compute_dtype(torch.float32)
 
     # -- MI355X-specific knobs (not in the reference) ------------------------------------------------------
-    def quantize_fp8(self, calib, headroom=2.0, exclude=()):
+    def quantize_fp8(self, calib, headroom=2.0, exclude=(), percentile=None):
         """fp8 inference (BASELINE configs[4]; the reference has no counterpart - trainer.py:223 is fp16 autocast only).  Every convolution
         that runs on the implicit-GEMM kernel (`Conv.run` on the bf16 MFMA path) switches to e4m3 operands: weights with per-output-channel
         scales (mgdt_conv_pack_fp8), activations with one power-of-two multiplier per convolution, chosen so that `headroom` x the largest
         |input| seen on the calibration images `calib` (one batch or a list of batches) lands at the top of the e4m3 range (448).  Activations
         stay bf16 in HBM; the block kernels (stem, CSP / MSPA blocks, ConvNeXt MLP, injection, detect tail) stay bf16.  `exclude`: substrings of
         module names (as in `named_modules()`, e.g. 'model.22.' = the Detect head) whose convolutions keep bf16 operands - the usual mixed-precision
-        policy when the last layers decide the score ranking.  Returns the {module name: multiplier} table.  `dequantize_fp8()` restores the bf16 path."""
+        policy when the last layers decide the score ranking.  `percentile` (e.g. 99.99): the activation range is that percentile of |input| instead
+        of its maximum (values beyond saturate at +-448) - with `headroom=1.0` this spends the e4m3 range on the bulk of the distribution.
+        Returns the {module name: multiplier} table.  `dequantize_fp8()` restores the bf16 path."""
         import math
         self.set_compute_dtype(torch.bfloat16)
         was_training = self.training
         self.eval()
         self.dequantize_fp8()
         stats = {}
-        ops.Q8_CALIB = stats
+        ops.Q8_CALIB, ops.Q8_CALIB_PCT = stats, percentile
         try:
             with torch.no_grad():
                 for xb in (calib if isinstance(calib, (list, tuple)) else [calib]):
                     self._predict_once(xb)
         finally:
-            ops.Q8_CALIB = None
+            ops.Q8_CALIB, ops.Q8_CALIB_PCT = None, None
             self.train(was_training)
         names = {m: n for n, m in self.named_modules()}
         table = {}

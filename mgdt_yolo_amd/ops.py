@@ -188,6 +188,7 @@ class PackedConvFp8:
 
 
 Q8_CALIB = None    # dict module -> running max|input| while BaseModel.quantize_fp8() runs its calibration batches
+Q8_CALIB_PCT = None  # None: the maximum of |input|; a number: that percentile of |input| (per batch, the largest over the batches)
 
 
 def conv2d_fp8(x, pk, stride, act, out=None, x2=None, r1=None, r2=None, in_scale=None, in_shift=None):

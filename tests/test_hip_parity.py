@@ -2174,6 +2174,13 @@ def test_map50_parity_with_the_cpu_reference_pipeline():
     t = m.quantize_fp8(calib, exclude=(head,))                       # mixed policy: the Detect head's convolutions keep bf16 operands
     assert t and not any(k.startswith(head[:-1]) for k in t)
     got['fp8_head_bf16'] = hip_map(m, xd.to(torch.bfloat16))
+    extra = {}
+    for tag, kw in (('fp8 max, headroom 1', dict(headroom=1.0)), ('fp8 p99.99, headroom 1', dict(headroom=1.0, percentile=99.99)),
+                    ('fp8 p99.9, headroom 1', dict(headroom=1.0, percentile=99.9)), ('fp8 p99.99, headroom 1, head bf16', dict(headroom=1.0, percentile=99.99, exclude=(head,)))):
+        m.quantize_fp8(calib, **kw)                                   # calibration variants: reported, not asserted
+        extra[tag] = hip_map(m, xd.to(torch.bfloat16))
+    for k, (a50, a5095) in extra.items():
+        print(f'HIP {k}: mAP50 {a50:.4f} (diff {a50 - ref50:+.4f})  mAP50-95 {a5095:.4f} (diff {a5095 - ref5095:+.4f})')
     for k, (a50, a5095) in got.items():
         print(f'HIP {k}: mAP50 {a50:.4f} (diff {a50 - ref50:+.4f})  mAP50-95 {a5095:.4f} (diff {a5095 - ref5095:+.4f})')
     for k, (a50, a5095) in got.items():
