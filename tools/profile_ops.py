@@ -34,13 +34,13 @@ with torch.no_grad():
 n = len(p.rows) // a.reps
 print(f'{n} launches per step; dtype {a.dtype} batch {a.batch} {a.imgsz}x{a.imgsz}')
 tot = 0.0
-print(f'{"#":>3} {"op":<22}{"shape (b,cin,h,w,cout,k,s)":<34}{"us":>9}{"GB/s":>9}{"TF/s":>8}')
+print(f'{"#":>3} {"op":<26}{"shape (b,cin,h,w,cout,k,s)":<34}{"us":>9}{"GB/s":>9}{"TF/s":>8}')
 for i in range(n):
     name, meta = p.rows[i][0], p.rows[i][1]
     us = sum(p.rows[i + r * n][2] for r in range(a.reps)) / a.reps * 1e3
     tot += us
     if meta:
-        print(f'{i:>3} {name:<22}{str(meta["shape"]):<34}{us:9.1f}{meta["bytes"] / us / 1e3:9.0f}{meta["flops"] / us / 1e6:8.1f}')
+        print(f'{i:>3} {name:<26}{str(meta["shape"]):<34}{us:9.1f}{meta["bytes"] / us / 1e3:9.0f}{meta["flops"] / us / 1e6:8.1f}')
     else:
-        print(f'{i:>3} {name:<22}{"":<34}{us:9.1f}')
+        print(f'{i:>3} {name:<26}{"":<34}{us:9.1f}')
 print(f'total {tot:.1f} us per step (sum of launches, eager)')
