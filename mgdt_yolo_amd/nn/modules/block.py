@@ -20,8 +20,8 @@ def _plain_block(first, last, bottlenecks):
     """True when a CSP block is made of what mgdt_csp_block_fwd computes: 1x1 Conv+BN+act at both ends, bottlenecks of two dense 3x3 Conv+BN
     with the same activation and one shortcut setting."""
     def conv_ok(c, k):
-        return (isinstance(c, Conv) and hasattr(c, 'bn') and c.conv.kernel_size == (k, k) and c.conv.stride == (1, 1) and c.conv.groups == 1
-                and c.conv.bias is None and act_code(c.act) == a0)
+        return (isinstance(c, Conv) and c.plain_affine() and c.conv.kernel_size == (k, k) and c.conv.stride == (1, 1) and c.conv.groups == 1
+                and act_code(c.act) == a0)
     try:
         a0 = act_code(first.act)
     except RuntimeError:
@@ -195,14 +195,13 @@ class MSPA_C2f(HipModule):
     def _chain_ok(self):
         """the three front convs are plain 1x1 Conv+BN with one activation (what mgdt_pw_chain3_fwd computes)"""
         cs = list(self.convs)[:3]
-        return all(hasattr(c, 'bn') and c.conv.kernel_size == (1, 1) and c.conv.groups == 1 and c.conv.in_channels == self.inwidth
+        return all(c.plain_affine() and c.conv.kernel_size == (1, 1) and c.conv.groups == 1 and c.conv.in_channels == self.inwidth
                    and c.conv.out_channels == self.inwidth and act_code(c.act) == act_code(cs[0].act) for c in cs)
 
     def _packed_chain(self, dtype):
         cs = list(self.convs)[:3]
-        tens = [t for c in cs for t in (c.conv.weight, c.conv.bias, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var)]
-        return self._cached(('chain', dtype), tens, lambda: ops.PackedPwChain(
-            [(c.conv.weight, c.conv.bias, (c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.eps)) for c in cs], dtype))
+        tens = [t for c in cs for t in c.affine_tensors()]
+        return self._cached(('chain', dtype), tens, lambda: ops.PackedPwChain([(c.conv.weight, c.conv.bias, c.bn_tuple()) for c in cs], dtype))
 
     def backward(self, g):
         out, attn, part, xshape = self._ctx.pop()
@@ -429,25 +428,27 @@ class InjectionMultiSum_Auto_pool(HipModule):
     def _merged_global(self, g, xq=None):
         """PackedConv of cat(global_act, global_embedding) along cout, or None when they are not two plain 1x1 Conv+BN(no act) layers."""
         a, b = self.global_act, self.global_embedding
-        ok = all(hasattr(m, 'bn') and act_code(m.act) == ops.ACT_NONE and m.conv.kernel_size == (1, 1) and m.conv.groups == 1 and m.conv.bias is None
-                 for m in (a, b))
+        ok = all(m.plain_affine() and act_code(m.act) == ops.ACT_NONE and m.conv.kernel_size == (1, 1) and m.conv.groups == 1 for m in (a, b))
         dt = a.out_dtype(g)
-        if not ok or a.bn.eps != b.bn.eps or a.conv.out_channels % 8 or not ops.conv_can_mfma(g, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels,
-                                                                                            1, 1, 1, dt):
+        fused = not hasattr(a, 'bn')
+        if (not ok or fused != (not hasattr(b, 'bn')) or (not fused and a.bn.eps != b.bn.eps) or a.conv.out_channels % 8
+                or not ops.conv_can_mfma(g, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels, 1, 1, 1, dt)):
             return None
-        tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
+        tens = [t for m in (a, b) for t in m.affine_tensors()]
         cat = lambda fn: torch.cat([fn(a).detach().float(), fn(b).detach().float()])
-        bn = lambda: (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        zb = lambda m: m.conv.bias if m.conv.bias is not None else torch.zeros(m.conv.out_channels, device=m.conv.weight.device)
+        bn = lambda: None if fused else (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        cb = lambda: cat(zb) if fused else None                # after fuse(): the folded biases ride on the merged conv
         if xq is not None:      # the e4m3 panel of the same merged convolution (quantize_fp8)
-            return self._cached(('gaf', 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), None, bn(), 1, xq))
-        return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), None, bn(), 1, dt))
+            return self._cached(('gaf', 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), cb(), bn(), 1, xq))
+        return self._cached(('gaf', dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), cb(), bn(), 1, dt))
 
     def forward_into_conv(self, x, conv):
         """Injection + the 1x1 Conv+BN+act `conv` that consumes it (C2f.cv1) in one launch; returns conv's output, or None when the pair is
         not covered (the caller then runs the two modules as usual).  Eval, bf16, up-sampling branch only."""
         x_l, x_g = x
         le = self.local_embedding
-        if self.training or not isinstance(conv, Conv) or not hasattr(conv, 'bn') or not hasattr(le, 'bn'):
+        if self.training or not isinstance(conv, Conv) or not conv.plain_affine() or not le.plain_affine():
             return None
         if ops.Q8_CALIB is not None or self.__dict__.get('_q8') or conv.__dict__.get('_q8') or le.__dict__.get('_q8'):
             return None                                      # fp8 calibration / fp8 operands: the per-site path
@@ -456,7 +457,7 @@ class InjectionMultiSum_Auto_pool(HipModule):
         g = x_g[:, c0:c0 + self.global_inp[self.flag]]
         pk2g = self._merged_global(g)
         if (pk2g is None or dt != torch.bfloat16 or act_code(le.act) != ops.ACT_NONE or le.conv.kernel_size != (1, 1)
-                or le.conv.groups != 1 or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1) or conv.conv.groups != 1 or conv.conv.bias is not None
+                or le.conv.groups != 1 or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1) or conv.conv.groups != 1
                 or conv.conv.in_channels != le.conv.out_channels):
             return None
         oc = self.global_act.conv.out_channels
@@ -471,10 +472,8 @@ class InjectionMultiSum_Auto_pool(HipModule):
             ga, gf = gaf[:, :oc], gaf[:, oc:]
             if ga.stride() != gf.stride():
                 return None
-        tens = [conv.conv.weight, conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var]
-        pk2 = conv._cached(('acc_order', dt), tens, lambda: ops.PackedConv(
-            conv.conv.weight.detach()[:, ops.acc_order_index(conv.conv.in_channels, conv.conv.weight.device)], None,
-            (conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var, conv.bn.eps), 1, dt))
+        pk2 = conv._cached(('acc_order', dt), conv.affine_tensors(), lambda: ops.PackedConv(
+            conv.conv.weight.detach()[:, ops.acc_order_index(conv.conv.in_channels, conv.conv.weight.device)], conv.conv.bias, conv.bn_tuple(), 1, dt))
         out = ops.new_act(b, conv.conv.out_channels, h, w, dt, x_l.device)
         if in_launch:
             return ops.conv1x1_inject_conv(x_l, le.packed(dt, direct=False), None, None, pk2, act_code(conv.act), out, gsrc=g, pkg=pk2g)
@@ -497,7 +496,7 @@ class InjectionMultiSum_Auto_pool(HipModule):
             gf = f(self.global_embedding)(g)
         le = self.local_embedding
         dt = le.out_dtype(x_l)
-        if (not train and hasattr(le, 'bn') and act_code(le.act) == ops.ACT_NONE and le.conv.kernel_size == (1, 1) and le.conv.groups == 1
+        if (not train and le.plain_affine() and act_code(le.act) == ops.ACT_NONE and le.conv.kernel_size == (1, 1) and le.conv.groups == 1
                 and ops.conv1x1_inject_supported(x_l, le.conv.out_channels, ga, dt) and ga.stride() == gf.stride()):
             return ops.conv1x1_inject(x_l, le.packed(dt, direct=False), ga, gf)   # local map never leaves the chip
         local = f(le)(x_l)

@@ -96,6 +96,33 @@ class Conv(HipModule):
         self.bn = nn.BatchNorm2d(c2)
         self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
 
+    # -- the conv's affine part, before and after BaseModel.fuse() -----------------------------------
+    def plain_affine(self):
+        """True for the two forms the block-level kernels take: bias-free conv + BatchNorm (as built), or - after `fuse()` (tasks.py:121-146:
+        `bn` deleted, the folded bias on the conv) - conv + bias.  (the fused model AutoBackend / the predictor run took none of the
+        block kernels.)"""
+        return (hasattr(self, 'bn') and self.conv.bias is None) or not hasattr(self, 'bn')
+
+    def bn_tuple(self):
+        """(gamma, beta, mean, var, eps) for the pack routines, or None after fuse() (the conv then carries its bias)"""
+        return (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps) if hasattr(self, 'bn') else None
+
+    def affine_tensors(self):
+        """every tensor a packed panel of this conv depends on (cache keys)"""
+        t = [self.conv.weight, self.conv.bias]
+        if hasattr(self, 'bn'):
+            t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return t
+
+    def folded_bn_like(self):
+        """the affine part as a BatchNorm tuple whatever the form: after fuse() the identity transform carrying the bias (gamma 1, mean 0,
+        var 1, eps 0: exact)"""
+        if hasattr(self, 'bn'):
+            return self.bn_tuple()
+        w = self.conv.weight
+        one, zero = torch.ones(w.shape[0], device=w.device), torch.zeros(w.shape[0], device=w.device)
+        return (one, self.conv.bias.detach().float() if self.conv.bias is not None else zero, zero, one, 0.0)
+
     # -- packed weights ------------------------------------------------------------------------------
     def _geometry(self):
         c = self.conv

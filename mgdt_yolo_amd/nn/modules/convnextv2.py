@@ -34,18 +34,16 @@ class ConvNeXtV2_Block(HipModule):
     def _tail_panel(conv, dim, dt):
         """PackedConv of a plain 1x1 Conv+BN+act over this block's `dim` channels with its input channels in accumulator order, or None"""
         from .conv import Conv, act_code
-        if (not ops.FUSED_CNX_TAIL or not isinstance(conv, Conv) or not hasattr(conv, 'bn') or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1)
-                or conv.conv.groups != 1 or conv.conv.bias is not None or conv.conv.in_channels != dim or conv.conv.out_channels > dim or conv.conv.out_channels % 4
+        if (not ops.FUSED_CNX_TAIL or not isinstance(conv, Conv) or not conv.plain_affine() or conv.conv.kernel_size != (1, 1) or conv.conv.stride != (1, 1)
+                or conv.conv.groups != 1 or conv.conv.in_channels != dim or conv.conv.out_channels > dim or conv.conv.out_channels % 4
                 or conv.__dict__.get('_q8') or ops.Q8_CALIB is not None or conv._forward_hooks):
             return None
         try:
             act_code(conv.act)
         except RuntimeError:
             return None
-        tens = [conv.conv.weight, conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var]
-        return conv._cached(('acc_order', dt), tens, lambda: ops.PackedConv(
-            conv.conv.weight.detach()[:, ops.acc_order_index(dim, conv.conv.weight.device)], None,
-            (conv.bn.weight, conv.bn.bias, conv.bn.running_mean, conv.bn.running_var, conv.bn.eps), 1, dt))
+        return conv._cached(('acc_order', dt), conv.affine_tensors(), lambda: ops.PackedConv(
+            conv.conv.weight.detach()[:, ops.acc_order_index(dim, conv.conv.weight.device)], conv.conv.bias, conv.bn_tuple(), 1, dt))
 
     def backward(self, g):
         x, u, t1, y1, t2, t3, S, pw1, pw2, dw, gb = self._ctx.pop()

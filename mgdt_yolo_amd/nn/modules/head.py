@@ -122,17 +122,20 @@ class Detect(HipModule):
         """PackedConv of cat(cv2[i][0], cv3[i][0]) along cout (BN folded per branch), or None when the pair is not two plain
         3x3 Conv+BN+SiLU layers the MFMA kernel takes."""
         a, b = self.cv2[i][0], self.cv3[i][0]
-        ok = all(isinstance(m, Conv) and hasattr(m, 'bn') and isinstance(m.act, nn.SiLU) and m.conv.kernel_size == (3, 3) and m.conv.stride == (1, 1)
-                 and m.conv.groups == 1 and m.conv.bias is None for m in (a, b))
-        if not ok or a.bn.eps != b.bn.eps or a.conv.out_channels % 8 or not ops.conv_can_mfma(xi, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels,
-                                                                                            3, 1, 1, dt):
+        ok = all(isinstance(m, Conv) and m.plain_affine() and isinstance(m.act, nn.SiLU) and m.conv.kernel_size == (3, 3) and m.conv.stride == (1, 1)
+                 and m.conv.groups == 1 for m in (a, b))
+        fused = ok and not hasattr(a, 'bn')
+        if (not ok or fused != (not hasattr(b, 'bn')) or (not fused and a.bn.eps != b.bn.eps) or a.conv.out_channels % 8
+                or not ops.conv_can_mfma(xi, a.conv.in_channels, a.conv.out_channels + b.conv.out_channels, 3, 1, 1, dt)):
             return None
-        tens = [t for m in (a, b) for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)]
+        tens = [t for m in (a, b) for t in m.affine_tensors()]
         cat = lambda f: torch.cat([f(a).detach().float(), f(b).detach().float()])
-        bn = lambda: (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        zb = lambda m: m.conv.bias if m.conv.bias is not None else torch.zeros(m.conv.out_channels, device=m.conv.weight.device)
+        bn = lambda: None if fused else (cat(lambda m: m.bn.weight), cat(lambda m: m.bn.bias), cat(lambda m: m.bn.running_mean), cat(lambda m: m.bn.running_var), a.bn.eps)
+        cb = lambda: cat(zb) if fused else None                # after fuse(): the folded biases ride on the merged conv
         if xq is not None:      # the e4m3 panel of the same merged convolution (quantize_fp8)
-            return self._cached(('first01', i, 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), None, bn(), 3, xq))
-        return self._cached(('first01', i, dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), None, bn(), 3, dt))
+            return self._cached(('first01', i, 'fp8', float(xq)), tens, lambda: ops.PackedConvFp8(cat(lambda m: m.conv.weight), cb(), bn(), 3, xq))
+        return self._cached(('first01', i, dt), tens, lambda: ops.PackedConv(cat(lambda m: m.conv.weight), cb(), bn(), 3, dt))
 
     def backward(self, grads):
         """grads: list of d loss / d raw head maps (one per level, NHWC).  Returns the list of input gradients."""

@@ -84,8 +84,7 @@ class BaseModel(nn.Module):
         if not self.training and self._stem_fusable(x):
             # layers 0 and 1 (two stride-2 3x3 Convs) in one launch: layer 0's map never reaches HBM (mgdt_stem2_fwd)
             m0, m1 = self.model[0], self.model[1]
-            pk0 = m0._cached(('stem2',), [m0.conv.weight, m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var],
-                             lambda: ops.PackedStem2(m0.conv.weight, (m0.bn.weight, m0.bn.bias, m0.bn.running_mean, m0.bn.running_var, m0.bn.eps)))
+            pk0 = m0._cached(('stem2',), m0.affine_tensors(), lambda: ops.PackedStem2(m0.conv.weight, m0.folded_bn_like()))
             x = ops.stem2(x, pk0, m1.packed(torch.bfloat16, direct=False))
             y = [None, x if 1 in self.save else None]
             layers = list(self.model)[2:]
@@ -203,8 +202,8 @@ class BaseModel(nn.Module):
             return False
         m0, m1 = self.model[0], self.model[1]
         for m, (ci, co) in ((m0, (3, 16)), (m1, (16, 32))):
-            if not (isinstance(m, Conv) and not isinstance(m, DWConv) and hasattr(m, 'bn') and isinstance(m.act, nn.SiLU) and m.f == -1 and not m._forward_hooks
-                    and m.conv.kernel_size == (3, 3) and m.conv.stride == (2, 2) and m.conv.padding == (1, 1) and m.conv.groups == 1 and m.conv.bias is None
+            if not (isinstance(m, Conv) and not isinstance(m, DWConv) and m.plain_affine() and isinstance(m.act, nn.SiLU) and m.f == -1 and not m._forward_hooks
+                    and m.conv.kernel_size == (3, 3) and m.conv.stride == (2, 2) and m.conv.padding == (1, 1) and m.conv.groups == 1
                     and m.conv.in_channels == ci and m.conv.out_channels == co):
                 return False
         return True

@@ -724,6 +724,35 @@ def test_e2e_fused_model_same_output():
     np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), atol=2e-4, rtol=0)
 
 
+def test_fused_bf16_model_takes_the_same_block_kernels():
+    """after `model.fuse()` (what AutoBackend(fuse=True) and the predictor run, tasks.py:121-146: `bn` deleted, folded bias on the conv) the
+    bf16 model must take the SAME launches as the unfused one - fused stem, CSP / ConvNeXt block kernels, injection + cv1, neck plan, Detect tail -
+    and give the same output: folding at pack time and folding in fuse() are the same fp32 arithmetic before the bf16 rounding of the panels."""
+    from mgdt_yolo_amd import ops
+    m = build_model('mspa_c2f_gd_yolov8', torch.bfloat16)
+    x = seeded_images(2, 320, 320, seed=GI.IMG_SEED).to(DEV).to(torch.bfloat16)
+
+    def run(model):
+        names = []
+        orig = ops._launch
+        with torch.no_grad():
+            model(x)                                             # panels are packed on first use
+            ops._launch = lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1]
+            try:
+                y, _ = model(x)
+            finally:
+                ops._launch = orig
+        return y.float(), names
+    y0, n0 = run(m)
+    y1, n1 = run(m.fuse())
+    assert m.is_fused() and not hasattr(m.model[0], 'bn')
+    assert n1 == n0, (len(n0), len(n1), sorted(set(n1) - set(n0)))
+    assert 'stem2_fwd' in n1 and n1.count('csp_block_fwd') == 5 and n1.count('cnx_block_fwd') == 3 and 'conv1x1_inject_conv_fwd' in n1 and 'detect_tail_fwd' in n1
+    err = (y1 - y0).abs()
+    print(f'fused vs unfused bf16 model: max |dy| boxes {err[:, :4].max().item():.3e} px, scores {err[:, 4:].max().item():.3e}; {len(n1)} launches')
+    assert err[:, :4].max().item() < 0.5 and err[:, 4:].max().item() < 2e-2
+
+
 @pytest.mark.parametrize('tag', list(GI.E2E_MODELS))
 def test_e2e_bf16_stated_tolerance(golden, tag):
     """bf16 throughput path: boxes within 1.5 px, conf within 0.05 of the fp32 reference (stated, not hidden)."""
