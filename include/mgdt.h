@@ -135,10 +135,13 @@ int mgdt_stem2_fwd(const mgdt_view* x, int x_dtype, const void* packed0, const f
  * (N, 16+nc, H, W) map and its decode (DFL expectation, dist2bbox, stride, sigmoid) into y[N][4+nc][a_total] at anchor offset a_off.
  * wb/bb, wc/bc: mgdt_conv_pack(c2, 16, 1, bf16) / mgdt_conv_pack(c3, nc, 1, bf16) with the conv biases.  reg_max must be 4 (this fork's
  * Detect); other heads keep mgdt_conv2d_fwd + mgdt_detect_decode_fwd.  best_keys: NULL, or [N][a_total] - per anchor the NMS key of its
- * best class (first maximal score, ops.py:225-226), see mgdt_nms_fwd. */
+ * best class (first maximal score, ops.py:225-226), see mgdt_nms_fwd.  wb3 / bb3: NULL, or mgdt_conv_pack(16, 16, 3, bf16) of the box branch's second
+ * Conv (cv2[i][1], head.py:150: 3x3, BN, SiLU) - tb is then THAT conv's input and the conv runs inside this launch; wb must then be packed from the
+ * final 1x1's weight zero-padded to 32 input channels (its 16 real ones in the accumulator order of mgdt_conv1x1_inject_conv_fwd's note). */
 int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, int dtype);
 int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
-                         float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys, mgdt_stream s);
+                         float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys,
+                         const void* wb3, const float* bb3, mgdt_stream s);
 
 /* ---- a whole CSP block (MSPA_C2f / C2f) in one launch, bf16 inference (nn/modules/block.py:187-287, :514-526):
  *   mode 0 (MSPA_C2f): front = the three chained 1x1 convs of mgdt_pw_chain3_fwd (blob of mgdt_pw_chain_pack), bottleneck input

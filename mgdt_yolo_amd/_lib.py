@@ -78,7 +78,7 @@ PROTOTYPES = {
     'mgdt_stem2_pack': (_i, [_vp, _vp, _vp]),
     'mgdt_stem2_fwd': (_i, [VP, _i, _vp, _vp, _vp, _vp, VP, _vp]),
     'mgdt_detect_tail_supported': (_i, [_i, _i, _i, _i, _i]),
-    'mgdt_detect_tail_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _f, _i, _i, VP, _vp, _vp, _vp]),
+    'mgdt_detect_tail_fwd': (_i, [VP, VP, _vp, _vp, _vp, _vp, _i, _f, _i, _i, VP, _vp, _vp, _vp, _vp, _vp]),
     'mgdt_csp_block_supported': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'mgdt_csp_block_tiles': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mgdt_csp_block_fwd': (_i, [_i, VP, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, VP, _vp, _i, _vp]),

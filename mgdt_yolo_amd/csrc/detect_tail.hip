@@ -18,6 +18,7 @@ struct DtArgs {
   const char* wb; const float* bb; const char* wc; const float* bc;
   float* y;
   unsigned long long* best;            // optional [N][a_total]: NMS key of every anchor's best class
+  const char* wb3; const float* bb3;   // optional: the box branch's SECOND 3x3 Conv+BN+SiLU (c2 -> c2 = 16) evaluated here; tb is then ITS input
   int N, H, W, HW, c2, c3, nc, kch, nbc, units_per_img, units, a_off, a_total;
   float stride;
   FastDiv fd_w;
@@ -32,12 +33,18 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
   char* wcl = smem + 1024;                                // cls panel: kch x nbc blocks of 1 KiB
   float* biasl = (float*)(wcl + (size_t)a.kch * a.nbc * 1024);       // [16] box | [nbc*16] cls
   float* ytile = biasl + 16 + a.nbc * 16;                 // [4 waves][4+nc][DT_LD]
+  char* wb3l = (char*)(ytile + (size_t)4 * (4 + a.nc) * DT_LD);      // box 3x3 panel: 5 K chunks x 1 block of 1 KiB (+ its bias[16])
+  float* bias3l = (float*)(wb3l + 5 * 1024);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   for (int i = tid; i < 64; i += DT_THREADS) ((uint4*)wbl)[i] = ((const uint4*)a.wb)[i];
   for (int i = tid; i < a.kch * a.nbc * 64; i += DT_THREADS) ((uint4*)wcl)[i] = ((const uint4*)a.wc)[i];
   for (int i = tid; i < 16 + a.nbc * 16; i += DT_THREADS) biasl[i] = i < 16 ? a.bb[i] : a.bc[i - 16];
+  if (a.wb3) {
+    for (int i = tid; i < 5 * 64; i += DT_THREADS) ((uint4*)wb3l)[i] = ((const uint4*)a.wb3)[i];
+    if (tid < 16) bias3l[tid] = a.bb3[tid];
+  }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tb, 0, a.tb_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tc, 0, a.tc_bytes, 0x00020000);
@@ -59,7 +66,26 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
       const int co = pv ? n * a.csn + oy * a.csh + ox * a.csw : MGDT_OOB;
       const int fo = pv ? n * a.fsn + oy * a.fsh + ox * a.fsw : MGDT_OOB;
       // ---- box branch: 16 outputs = 4 sides x 4 bins; lane (r, g): bins of side g
-      const bf16x8 Bb = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, (bo | boff) < 0 ? (uint32_t)MGDT_OOB : (uint32_t)(bo + boff), 0, 0));
+      bf16x8 Bb;
+      if (a.wb3) {
+        // the box branch's second conv (3x3, 16 -> 16, BN + SiLU: head.py:150 cv2[i][1]) as an implicit GEMM over tb = its input: K = 9 taps x 2
+        // pieces = 18 pieces in 5 chunks; the result (rounded to bf16 like the stored map) is the B operand of the final 1x1 (K slots e < 4)
+        bf16x8 B3[5];
+#pragma unroll
+        for (int kc = 0; kc < 5; ++kc) {
+          const int p = kc * 4 + g, tap = p >> 1, cp = p & 1;
+          const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+          const bool ok = pv && tap < 9 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          B3[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, ok ? (uint32_t)(n * a.bsn + iy * a.bsh + ix * a.bsw + cp * 16) : (uint32_t)MGDT_OOB, 0, 0));
+        }
+        f32x4 acc3 = *(const f32x4*)(bias3l + 4 * g);
+#pragma unroll
+        for (int kc = 0; kc < 5; ++kc) acc3 = mma(*(const bf16x8*)(wb3l + kc * 1024 + lane * 16), B3[kc], acc3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Bb[e] = e < 4 ? (bf16)(acc3[e] * fast_sigmoid(acc3[e])) : (bf16)0.f;
+      } else {
+        Bb = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(brs, (bo | boff) < 0 ? (uint32_t)MGDT_OOB : (uint32_t)(bo + boff), 0, 0));
+      }
       bf16x8 Bc[4];
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
@@ -150,7 +176,8 @@ extern "C" int mgdt_detect_tail_supported(int c2, int c3, int nc, int reg_max, i
 }
 
 extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, const void* wb, const float* bb, const void* wc, const float* bc, int nc,
-                                    float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys, mgdt_stream s) {
+                                    float stride, int a_off, int a_total, const mgdt_view* feat, float* y, unsigned long long* best_keys,
+                                    const void* wb3, const float* bb3, mgdt_stream s) {
   if (!view_ok(tb) || !view_ok(tc) || !view_ok(feat) || !wb || !bb || !wc || !bc || !y) MGDT_FAIL(MGDT_BAD_ARG, "detect_tail: null/empty argument");
   if (!mgdt_detect_tail_supported(tb->c, tc->c, nc, 4, MGDT_BF16)) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: c2=%d c3=%d nc=%d not covered", tb->c, tc->c, nc);
   if (feat->c != 16 + nc || tb->n != tc->n || tb->h != tc->h || tb->w != tc->w || feat->n != tb->n || feat->h != tb->h || feat->w != tb->w ||
@@ -171,11 +198,13 @@ extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, co
   if (!fits) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: views must be 16-byte aligned NHWC (sc == 1) below 2 GiB");
   a.feat = (char*)fp;
   a.wb = (const char*)wb; a.bb = bb; a.wc = (const char*)wc; a.bc = bc; a.y = y; a.best = best_keys;
+  a.wb3 = (const char*)wb3; a.bb3 = bb3;
+  if (wb3 && (!bb3 || tb->c != 16)) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: the in-launch 3x3 box conv is built for 16 -> 16 channels");
   a.N = tb->n; a.H = tb->h; a.W = tb->w; a.HW = tb->h * tb->w; a.c2 = tb->c; a.c3 = tc->c; a.nc = nc;
   a.kch = cdiv(tc->c, 32); a.nbc = cdiv(nc, 16);
   a.units_per_img = cdiv(a.HW, 32); a.units = a.N * a.units_per_img;
   a.a_off = a_off; a.a_total = a_total; a.stride = stride; a.fd_w = make_fastdiv((uint32_t)tb->w);
-  const size_t lds = 1024 + (size_t)a.kch * a.nbc * 1024 + (size_t)(16 + a.nbc * 16) * 4 + (size_t)4 * (4 + nc) * DT_LD * 4;
+  const size_t lds = 1024 + (size_t)a.kch * a.nbc * 1024 + (size_t)(16 + a.nbc * 16) * 4 + (size_t)4 * (4 + nc) * DT_LD * 4 + 5 * 1024 + 64;
   if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: nc=%d needs %zu B of LDS", nc, lds);
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {

@@ -83,7 +83,19 @@ class Detect(HipModule):
                 xq = self.q8_site(('first01', i), xi) if feat.dtype == torch.bfloat16 else None
                 t01 = ops.conv2d(xi, pk01, 1, ops.ACT_SILU) if xq is None else ops.conv2d_fp8(xi, self._merged_first(i, xi, feat.dtype, xq), 1, ops.ACT_SILU)
                 c2 = self.cv2[i][0].conv.out_channels
-                tb, tc = self.cv2[i][1](t01[:, :c2]), self.cv3[i][1](t01[:, c2:])
+                tc = self.cv3[i][1](t01[:, c2:])
+                box3 = self._box3_in_tail(i, t01[:, :c2], tc, feat.dtype)
+                if box3 is not None:
+                    # the box branch's second 3x3 conv (16 -> 16) runs inside the tail launch: its input is handed over instead of its output
+                    pk3, pkb_pad = box3
+                    pkc = self._cached((id(self.cv3[i][2]), feat.dtype), [self.cv3[i][2].weight, self.cv3[i][2].bias],
+                                       lambda c=self.cv3[i][2]: ops.PackedConv(c.weight, c.bias, None, 1, feat.dtype))
+                    ops.detect_tail(t01[:, :c2], tc, pkb_pad, pkc, self.nc, strides[i], a_off, feat, y, best, pk3=pk3)
+                    decoded[i] = True
+                    a_off += h * w
+                    x[i] = feat
+                    continue
+                tb = self.cv2[i][1](t01[:, :c2])
             else:
                 tb = self.cv2[i][1](self.cv2[i][0](xi))      # Conv.forward: eval -> fused run, train -> batch-stat BN + ctx
                 tc = self.cv3[i][1](self.cv3[i][0](xi))
@@ -117,6 +129,24 @@ class Detect(HipModule):
         if all(decoded):
             ops.attach_best_keys(y, best)        # every level went through the tail kernel: non_max_suppression(y) skips its best-class scan
         return y if self.export else (y, x)
+
+    def _box3_in_tail(self, i, tb_in, tc, dt):
+        """(panel of cv2[i][1], zero-padded accumulator-order panel of cv2[i][2]) when the box branch's second conv can run inside the Detect tail
+        launch: eval, bf16, 16 -> 16 channels, plain 3x3 Conv + BN/bias + SiLU, reg_max 4; else None."""
+        m3, m1 = self.cv2[i][1], self.cv2[i][2]
+        if (self.training or not ops.FUSED_DETECT_BOX3 or dt != torch.bfloat16 or not isinstance(m3, Conv) or not m3.plain_affine() or not isinstance(m3.act, nn.SiLU)
+                or m3.conv.kernel_size != (3, 3) or m3.conv.stride != (1, 1) or m3.conv.groups != 1 or m3.conv.in_channels != 16 or m3.conv.out_channels != 16
+                or m3._forward_hooks or m3.__dict__.get('_q8') or ops.Q8_CALIB is not None or tb_in.shape[1] != 16
+                or not ops.detect_tail_supported(tb_in, tc, self.nc, self.reg_max, dt)):
+            return None
+        pk3 = m3.packed(dt, direct=False)
+
+        def pad_pack():
+            w = m1.weight.detach().float().reshape(m1.out_channels, 16)
+            wp = torch.zeros(m1.out_channels, 32, device=w.device)
+            wp[:, :16] = w                                     # channels 16..31 do not exist: zero weights
+            return ops.PackedConv(wp[:, ops.acc_order_index(32, w.device)].reshape(m1.out_channels, 32, 1, 1), m1.bias, None, 1, dt)
+        return pk3, self._cached((id(m1), dt, 'acc32'), [m1.weight, m1.bias], pad_pack)
 
     def _merged_first(self, i, xi, dt, xq=None):
         """PackedConv of cat(cv2[i][0], cv3[i][0]) along cout (BN folded per branch), or None when the pair is not two plain

@@ -746,15 +746,19 @@ def detect_tail_supported(tb, tc, nc, reg_max, dtype):
                 L.lib().mgdt_detect_tail_supported(tb.shape[1], tc.shape[1], int(nc), int(reg_max), dtype_code(dtype)))
 
 
-def detect_tail(tb, tc, pkb, pkc, nc, stride, a_off, feat, y, best=None):
+FUSED_DETECT_BOX3 = True   # tests flip this: the box branch's second 3x3 conv inside the Detect tail launch vs a launch of its own
+
+
+def detect_tail(tb, tc, pkb, pkc, nc, stride, a_off, feat, y, best=None, pk3=None):
     """mgdt_detect_tail_fwd: final 1x1 convs of both branches + raw map `feat` + decode into y (+ per-anchor best-class NMS keys into `best`,
-    int64 [B][A], when given)."""
+    int64 [B][A], when given).  pk3: PackedConv of the box branch's second 3x3 conv - `tb` is then that conv's 16-channel input and `pkb` the
+    final 1x1 packed over 32 zero-padded input channels."""
     if _PROF is not None:
         b, _, h, w = tb.shape
         _META['detect_tail_fwd'] = dict(shape=(b, tb.shape[1] + tc.shape[1], h, w, 16 + nc, 1, 1), flops=2.0 * b * h * w * (tb.shape[1] * 16 + tc.shape[1] * nc),
                                         bytes=float((tb.numel() + tc.numel() + feat.numel()) * 2 + b * (4 + nc) * h * w * 4))
     _launch('detect_tail_fwd', 'mgdt_detect_tail_fwd', vp(tb), vp(tc), ptr(pkb.w), ptr(pkb.bias), ptr(pkc.w), ptr(pkc.bias), int(nc), float(stride), int(a_off),
-            y.shape[2], vp(feat), ptr(y), ptr(best), stream())
+            y.shape[2], vp(feat), ptr(y), ptr(best), None if pk3 is None else ptr(pk3.w), None if pk3 is None else ptr(pk3.bias), stream())
 
 
 # ------------------------------------------------------------------ NMS

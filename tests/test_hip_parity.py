@@ -327,6 +327,43 @@ def test_injection_single_launch_matches_conv_plus_inject(cin, cout, hw, ghw):
     assert (y_fused - y_pair).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize('nc,hws', [(80, [(80, 80)]), (4, [(13, 11)]), (80, [(20, 24), (10, 12), (5, 6)])])
+def test_detect_box_branch_3x3_inside_the_tail_launch(nc, hws):
+    """The Detect box branch's second conv (cv2[i][1]: 3x3, 16 -> 16, BN, SiLU; head.py:150) evaluated inside mgdt_detect_tail_fwd (an implicit
+    GEMM over its input, the result rounded to bf16 as the stored map and chained into the final 1x1) against the same head with that conv as
+    its own launch: y (boxes / scores), the raw maps and the NMS keys must agree to rounding (the K order of both GEMMs is unchanged)."""
+    from mgdt_yolo_amd import ops
+    from mgdt_yolo_amd.nn.modules import Detect
+    ch = (64, 128, 256)[:len(hws)]
+    m = seed_state_dict_(Detect(nc, ch), 2).eval().to(DEV)
+    m.stride = torch.tensor([8.0, 16.0, 32.0][:len(hws)])
+    m.apply(lambda t: setattr(t, '_cdtype', torch.bfloat16) if hasattr(t, 'out_dtype') else None)
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, c, *hw, generator=gen).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c, hw in zip(ch, hws)]
+    res = {}
+    with torch.no_grad():
+        for flag in (True, False):
+            ops.FUSED_DETECT_BOX3 = flag
+            try:
+                names = []
+                orig = ops._launch
+                m(list(xs))
+                ops._launch = lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1]
+                try:
+                    y, feats = m(list(xs))
+                finally:
+                    ops._launch = orig
+                res[flag] = (y.clone(), [f.clone() for f in feats], ops._best_keys_of(y, 2, y.shape[2]).clone(), names)
+            finally:
+                ops.FUSED_DETECT_BOX3 = True
+    (y1, f1, k1, n1), (y0, f0, k0, n0) = res[True], res[False]
+    assert len(n0) - len(n1) == len(hws), (n0, n1)
+    eb, es = (y1[:, :4] - y0[:, :4]).abs().max().item(), (y1[:, 4:] - y0[:, 4:]).abs().max().item()
+    ef = max((a.float() - b.float()).abs().max().item() for a, b in zip(f1, f0))
+    print(f'box 3x3 in the tail: boxes {eb:.3e} px, scores {es:.3e}, raw maps {ef:.3e}; launches {len(n0)} -> {len(n1)}')
+    assert eb < 5e-2 and es == 0.0 and ef < 3e-2 and torch.equal(k1, k0)
+
+
 @pytest.mark.parametrize('b,hw,ghw', [(32, (80, 80), (40, 40)), (2, (37, 45), (19, 23)), (3, (16, 16), (16, 16)), (1, (80, 80), (20, 20))])
 def test_injection_plus_c2f_cv1_single_launch_matches_two_launches(b, hw, ghw):
     """mgdt_conv1x1_inject_conv_fwd: the injection and the 1x1 Conv+BN+SiLU that is its only consumer (C2f.cv1) in one launch - the
