@@ -64,7 +64,7 @@ extern "C" int mgdt_sgd_step(float* p, const float* g, float* buf, const float* 
 }
 
 __global__ void ema_flat_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float d) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ema[i] = d * ema[i] + (1.f - d) * p[i];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ema[i] = d * ema[i] + (1.f - d) * p[i];   // v *= d; v += (1 - d) * w (torch_utils.py ModelEMA.update); this file is built with -ffp-contract=off
 }
 extern "C" int mgdt_ema_update(float* ema, const float* p, long n, float decay, mgdt_stream s) {
   if (!ema || !p || n <= 0) MGDT_FAIL(MGDT_BAD_ARG, "ema_update: null/empty argument");

@@ -352,12 +352,139 @@ __device__ __forceinline__ void spr_scale_cells(const T* __restrict__ x, long xs
   }
 }
 
+// Latency-lean prologue of spr_attn_scale_kernel (C <= 256, per-tile sums, fc weights small enough for LDS): every workgroup of the image repeats
+// it, so its length is a floor under the launch.  The first form walked the fc weights in global memory inside the dot products (one dependent
+// load per multiply-add) and reduced the partial sums four loads at a time: 13 us of the 17 us launch at 20x20x256 were prologue (phase
+// stamps, MGDT_SPR_DBG).  Here every global load - partial sums, both weight matrices, both biases - is issued before the first one is
+// consumed, the matrices go to LDS as padded rows, and fc1 reads them as float4 with `tpo` threads per output.
+// LDS: pvec [G][5 cw] (means in fc1's column order: cw whole-map means, then 4 bin means per channel) | hbuf [G hid] | obuf [C] | att [C] |
+//      w1s [hid][5 cw + 4] | w2s [cw][hid + 1] | b1s [hid] | b2s [cw]
+__device__ __forceinline__ void spr_prologue_fast(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                  const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int n, int nsplit, int tiles_x,
+                                                  int tiles_y, FastDiv fd_gst, FastDiv fd_tx, FastDiv fd_l4, const float* cnt, float* sm, float* red, float* att, unsigned long long* TS, int& nt) {
+#define SPR_STAMP() do { if (TS) TS[nt++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  const int tid = threadIdx.x, cw = C / G, hid = cw / 4, L = 5 * cw, L4 = L / 4, r1 = L + 4, r2 = hid + 1;
+  float* pvec = sm;
+  float* hbuf = sm + C * 5;
+  float* obuf = hbuf + G * hid;
+  float* w1s = att + C + ((4 - ((C * 7 + G * hid) & 3)) & 3);        // 16-byte aligned rows
+  float* w2s = w1s + hid * r1;
+  float* b1s = w2s + cw * r2;
+  float* b2s = b1s + hid;
+  // ---- every global load of the prologue, issued back to back
+  constexpr int PB = 16, WB = 6;
+  const int ph = 256 / C, c = tid % C, sp0 = tid / C;                 // threads per channel, this thread's channel and first slot
+  const float* pc = partial + (long)n * nsplit * C + c;
+  float pv[PB];
+#pragma unroll
+  for (int u = 0; u < PB; ++u) { const int sp = sp0 + u * ph; pv[u] = (sp0 < ph && sp < nsplit) ? pc[(long)sp * C] : 0.f; }
+  const int nw4 = hid * L4;
+  float4 wv[WB];
+#pragma unroll
+  for (int u = 0; u < WB; ++u) { const int i4 = tid + u * 256; wv[u] = i4 < nw4 ? ((const float4*)w1)[i4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  const float w2v = tid < cw * hid ? w2[tid] : 0.f;
+  const float b1v = tid < hid ? b1[tid] : 0.f, b2v = tid < cw ? b2[tid] : 0.f;
+  SPR_STAMP();
+  // ---- weights to LDS
+#pragma unroll
+  for (int u = 0; u < WB; ++u) {
+    const int i4 = tid + u * 256;
+    if (i4 < nw4) { const int row = (int)fdiv((uint32_t)i4, fd_l4); *(float4*)(w1s + row * r1 + (i4 - row * L4) * 4) = wv[u]; }
+  }
+  for (int i4 = tid + WB * 256; i4 < nw4; i4 += 256) { const int row = (int)fdiv((uint32_t)i4, fd_l4); *(float4*)(w1s + row * r1 + (i4 - row * L4) * 4) = ((const float4*)w1)[i4]; }
+  if (tid < cw * hid) w2s[(tid / hid) * r2 + tid % hid] = w2v;
+  for (int i = tid + 256; i < cw * hid; i += 256) w2s[(i / hid) * r2 + i % hid] = w2[i];
+  if (tid < hid) b1s[tid] = b1v;
+  if (tid < cw) b2s[tid] = b2v;
+  for (int i = tid + 256; i < cw; i += 256) b2s[i] = b2[i];
+  __builtin_amdgcn_s_waitcnt(0x0F70); SPR_STAMP();
+  // ---- per-tile sums -> 5 pooled means per channel (tile = ty * tiles_x + tx lies inside ONE pooling bin)
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add = [&](float v, int sp) __attribute__((always_inline)) {
+    const int tile = (int)fdiv((uint32_t)sp, fd_gst), ty = (int)fdiv((uint32_t)tile, fd_tx), tx = tile - ty * tiles_x;
+    const int bin = (2 * ty >= tiles_y ? 2 : 0) + (2 * tx >= tiles_x ? 1 : 0);
+    acc[0] += v;
+    acc[1] += bin == 0 ? v : 0.f;
+    acc[2] += bin == 1 ? v : 0.f;
+    acc[3] += bin == 2 ? v : 0.f;
+    acc[4] += bin == 3 ? v : 0.f;
+  };
+#pragma unroll
+  for (int u = 0; u < PB; ++u) add(pv[u], sp0 + u * ph);             // slots past the end were loaded as 0
+  if (sp0 < ph) {
+    for (int sp = sp0 + PB * ph; sp < nsplit; sp += PB * ph) {
+#pragma unroll
+      for (int u = 0; u < PB; ++u) pv[u] = sp + u * ph < nsplit ? pc[(long)(sp + u * ph) * C] : 0.f;
+#pragma unroll
+      for (int u = 0; u < PB; ++u) add(pv[u], sp + u * ph);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k * 256 + tid] = acc[k];
+  __syncthreads();
+  for (int o = tid; o < C * 5; o += 256) {
+    const int cc = o % C, k = o / C, gi = cc / cw, ci = cc - gi * cw;
+    float sum = 0.f;
+    for (int p = 0; p < ph; ++p) sum += red[k * 256 + p * C + cc];
+    pvec[gi * L + (k == 0 ? ci : cw + 4 * ci + (k - 1))] = sum / cnt[k];
+  }
+  __syncthreads();
+  SPR_STAMP();
+  // ---- fc1 + relu (spr_module.py:21-23): tpo threads share one output's dot product (float4 pieces, interleaved), summed by an xor butterfly
+  const int nout = G * hid;
+  int tpo = 64;
+  while (tpo > 1 && (256 / tpo < nout || tpo > L4)) tpo >>= 1;
+  const int opp = 256 / tpo;                                          // outputs per pass
+  for (int base = 0; base < nout; base += opp) {
+    const int o = base + tid / tpo, p = tid % tpo;
+    float a0 = 0.f, a1 = 0.f;
+    if (o < nout) {
+      const int gi = o / hid, hj = o - gi * hid;
+      const float4* wr = (const float4*)(w1s + hj * r1);
+      const float4* pg = (const float4*)(pvec + gi * L);
+      int i = p;
+      for (; i + tpo < L4; i += 2 * tpo) {
+        const float4 wa = wr[i], xa = pg[i], wb = wr[i + tpo], xb = pg[i + tpo];
+        a0 = fmaf(wa.w, xa.w, fmaf(wa.z, xa.z, fmaf(wa.y, xa.y, fmaf(wa.x, xa.x, a0))));
+        a1 = fmaf(wb.w, xb.w, fmaf(wb.z, xb.z, fmaf(wb.y, xb.y, fmaf(wb.x, xb.x, a1))));
+      }
+      if (i < L4) { const float4 wa = wr[i], xa = pg[i]; a0 = fmaf(wa.w, xa.w, fmaf(wa.z, xa.z, fmaf(wa.y, xa.y, fmaf(wa.x, xa.x, a0)))); }
+    }
+    float s = a0 + a1;
+    for (int m = tpo >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (o < nout && p == 0) hbuf[o] = fmaxf(s + b1s[o % hid], 0.f);
+  }
+  __syncthreads();
+  SPR_STAMP();
+  for (int o = tid; o < C; o += 256) {                                // fc2 + sigmoid
+    const int gi = o / cw, ci = o - gi * cw;
+    float s = b2s[ci];
+#pragma unroll 4
+    for (int hj = 0; hj < hid; ++hj) s = fmaf(w2s[ci * r2 + hj], hbuf[gi * hid + hj], s);
+    obuf[o] = 1.f / (1.f + expf(-s));
+  }
+  __syncthreads();
+  SPR_STAMP();
+  for (int ci = tid; ci < cw; ci += 256) {                            // softmax over the G groups (block.py:278)
+    float mx = -INFINITY;
+    for (int gi = 0; gi < G; ++gi) mx = fmaxf(mx, obuf[gi * cw + ci]);
+    float den = 0.f;
+    for (int gi = 0; gi < G; ++gi) { const float e = expf(obuf[gi * cw + ci] - mx); att[gi * cw + ci] = e; den += e; }
+    for (int gi = 0; gi < G; ++gi) att[gi * cw + ci] /= den;
+  }
+  __syncthreads();
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int C, int G, int H, int W,
                                                              const T* __restrict__ x, long xsn, long xsh, long xsw, T* __restrict__ y, long ysn, long ysh,
-                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit, int tiles_x, int tiles_y, SprPool pa, SprPool pb) {
+                                                             long ysw, FastDiv fd_q, FastDiv fd_w, int nsplit, int tiles_x, int tiles_y, SprPool pa, SprPool pb, FastDiv fd_gst,
+                                                             FastDiv fd_tx, FastDiv fd_l4, int fast, unsigned long long* dbg) {
   extern __shared__ float sm[];
+  unsigned long long TS[10]; int nt = 0;
+  auto stamp = [&]() __attribute__((always_inline)) { if (dbg) TS[nt++] = __builtin_amdgcn_s_memrealtime(); };
+  stamp();
   const int n = blockIdx.y, cw = C / G, hid = cw / 4;
   float* pooled = sm;               // [C][5] means
   float* hbuf = sm + C * 5;         // [G][hid]
@@ -365,73 +492,79 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
   float* att = obuf + C;            // [C] softmax over groups
   const int hs1 = bin_start(1, H, 2), he0 = bin_end(0, H, 2), ws1 = bin_start(1, W, 2), we0 = bin_end(0, W, 2);
   const float cnt[5] = {(float)H * W, (float)he0 * we0, (float)he0 * (W - ws1), (float)(H - hs1) * we0, (float)(H - hs1) * (W - ws1)};
-  if (tiles_x > 0) {
-    // per-tile sums written by mgdt_csp_block_fwd: partial[n][slot][c], slot = tile * gst + k, tile = ty * tiles_x + tx lies inside ONE pooling
-    // bin.  256 threads read coalesced rows of C floats with many loads in flight (a serial walk over hundreds of slots per value is
-    // latency-bound: it cost more than the block kernel itself), then the threads that share a channel are summed in a fixed order.
-    __shared__ float red[5 * 256];
-    const int gst = nsplit / (tiles_x * tiles_y);
-    for (int c0 = 0; c0 < C; c0 += 256) {
-      const int lanes_c = min(C - c0, 256);                     // channels handled in this pass
-      const int ph = 256 / lanes_c;                             // threads per channel (C is a multiple of 4, <= 256 typical)
-      const int c = c0 + threadIdx.x % lanes_c, sp0 = threadIdx.x / lanes_c;
-      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-      if (sp0 < ph) {
-        for (int sp = sp0; sp < nsplit; sp += ph) {
-          const float v = partial[((long)n * nsplit + sp) * C + c];
-          const int tile = sp / gst, ty = tile / tiles_x, tx = tile - ty * tiles_x;
-          const int bin = (2 * ty >= tiles_y ? 2 : 0) + (2 * tx >= tiles_x ? 1 : 0);
-          acc[0] += v;
-          acc[1] += bin == 0 ? v : 0.f;
-          acc[2] += bin == 1 ? v : 0.f;
-          acc[3] += bin == 2 ? v : 0.f;
-          acc[4] += bin == 3 ? v : 0.f;
+  __shared__ float red[5 * 256];
+  if (fast) {
+    spr_prologue_fast(partial, w1, b1, w2, b2, C, G, n, nsplit, tiles_x, tiles_y, fd_gst, fd_tx, fd_l4, cnt, sm, red, att, dbg ? TS : nullptr, nt);
+  } else {
+    if (tiles_x > 0) {
+      // per-tile sums written by mgdt_csp_block_fwd: partial[n][slot][c], slot = tile * gst + k, tile = ty * tiles_x + tx lies inside ONE pooling
+      // bin.  256 threads read coalesced rows of C floats with many loads in flight (a serial walk over hundreds of slots per value is
+      // latency-bound: it cost more than the block kernel itself), then the threads that share a channel are summed in a fixed order.
+      const int gst = nsplit / (tiles_x * tiles_y);
+      for (int c0 = 0; c0 < C; c0 += 256) {
+        const int lanes_c = min(C - c0, 256);                     // channels handled in this pass
+        const int ph = 256 / lanes_c;                             // threads per channel (C is a multiple of 4, <= 256 typical)
+        const int c = c0 + threadIdx.x % lanes_c, sp0 = threadIdx.x / lanes_c;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (sp0 < ph) {
+          for (int sp = sp0; sp < nsplit; sp += ph) {
+            const float v = partial[((long)n * nsplit + sp) * C + c];
+            const int tile = sp / gst, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int bin = (2 * ty >= tiles_y ? 2 : 0) + (2 * tx >= tiles_x ? 1 : 0);
+            acc[0] += v;
+            acc[1] += bin == 0 ? v : 0.f;
+            acc[2] += bin == 1 ? v : 0.f;
+            acc[3] += bin == 2 ? v : 0.f;
+            acc[4] += bin == 3 ? v : 0.f;
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < 5; ++k) red[k * 256 + threadIdx.x] = acc[k];
-      __syncthreads();
-      for (int o = threadIdx.x; o < lanes_c * 5; o += 256) {
-        const int cc = o % lanes_c, k = o / lanes_c;
+        for (int k = 0; k < 5; ++k) red[k * 256 + threadIdx.x] = acc[k];
+        __syncthreads();
+        for (int o = threadIdx.x; o < lanes_c * 5; o += 256) {
+          const int cc = o % lanes_c, k = o / lanes_c;
+          float sum = 0.f;
+          for (int p = 0; p < ph; ++p) sum += red[k * 256 + p * lanes_c + cc];
+          pooled[(c0 + cc) * 5 + k] = sum / cnt[k];
+        }
+        __syncthreads();
+      }
+    } else {
+      for (int i = threadIdx.x; i < C * 5; i += 256) {
         float sum = 0.f;
-        for (int p = 0; p < ph; ++p) sum += red[k * 256 + p * lanes_c + cc];
-        pooled[(c0 + cc) * 5 + k] = sum / cnt[k];
+        for (int sp = 0; sp < nsplit; ++sp) sum += partial[((long)n * nsplit + sp) * C * 5 + i];
+        pooled[i] = sum / cnt[i % 5];
       }
       __syncthreads();
     }
-  } else {
-    for (int i = threadIdx.x; i < C * 5; i += 256) {
-      float sum = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) sum += partial[((long)n * nsplit + sp) * C * 5 + i];
-      pooled[i] = sum / cnt[i % 5];
+    for (int o = threadIdx.x; o < G * hid; o += 256) {   // fc1 + relu (spr_module.py:21-23), as in spr_attn_kernel
+      int gi = o / hid, hj = o % hid;
+      const float* wr = w1 + (long)hj * 5 * cw;
+      float acc = b1[hj];
+      for (int c = 0; c < cw; ++c) acc = fmaf(wr[c], pooled[(gi * cw + c) * 5 + 0], acc);
+      for (int c = 0; c < cw; ++c)
+        for (int bn = 0; bn < 4; ++bn) acc = fmaf(wr[cw + c * 4 + bn], pooled[(gi * cw + c) * 5 + 1 + bn], acc);
+      hbuf[o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < C; o += 256) {
+      int gi = o / cw, c = o % cw;
+      float acc = b2[c];
+      for (int hj = 0; hj < hid; ++hj) acc = fmaf(w2[(long)c * hid + hj], hbuf[gi * hid + hj], acc);
+      obuf[o] = 1.f / (1.f + expf(-acc));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cw; c += 256) {   // softmax over the G groups (block.py:278)
+      float mx = -INFINITY;
+      for (int gi = 0; gi < G; ++gi) mx = fmaxf(mx, obuf[gi * cw + c]);
+      float den = 0.f;
+      for (int gi = 0; gi < G; ++gi) den += expf(obuf[gi * cw + c] - mx);
+      for (int gi = 0; gi < G; ++gi) att[gi * cw + c] = expf(obuf[gi * cw + c] - mx) / den;
     }
     __syncthreads();
   }
-  for (int o = threadIdx.x; o < G * hid; o += 256) {   // fc1 + relu (spr_module.py:21-23), as in spr_attn_kernel
-    int gi = o / hid, hj = o % hid;
-    const float* wr = w1 + (long)hj * 5 * cw;
-    float acc = b1[hj];
-    for (int c = 0; c < cw; ++c) acc = fmaf(wr[c], pooled[(gi * cw + c) * 5 + 0], acc);
-    for (int c = 0; c < cw; ++c)
-      for (int bn = 0; bn < 4; ++bn) acc = fmaf(wr[cw + c * 4 + bn], pooled[(gi * cw + c) * 5 + 1 + bn], acc);
-    hbuf[o] = fmaxf(acc, 0.f);
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < C; o += 256) {
-    int gi = o / cw, c = o % cw;
-    float acc = b2[c];
-    for (int hj = 0; hj < hid; ++hj) acc = fmaf(w2[(long)c * hid + hj], hbuf[gi * hid + hj], acc);
-    obuf[o] = 1.f / (1.f + expf(-acc));
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < cw; c += 256) {   // softmax over the G groups (block.py:278)
-    float mx = -INFINITY;
-    for (int gi = 0; gi < G; ++gi) mx = fmaxf(mx, obuf[gi * cw + c]);
-    float den = 0.f;
-    for (int gi = 0; gi < G; ++gi) den += expf(obuf[gi * cw + c] - mx);
-    for (int gi = 0; gi < G; ++gi) att[gi * cw + c] = expf(obuf[gi * cw + c] - mx) / den;
-  }
-  __syncthreads();
+  stamp();
+  auto fin = [&]() __attribute__((always_inline)) { if (dbg) { __builtin_amdgcn_s_waitcnt(0); stamp(); if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = TS[k]; } };
   {
     // pooled outputs with factors {4}, {2}, {4, 2}: the cell form does everything in one pass
     const int fa = pa.F, fb = pb.F, fm = max(fa, fb);
@@ -441,6 +574,7 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
       const SprPool big = fa == fm ? pa : (fb == fm ? pb : none), small = (fa && fa < fm) ? pa : ((fb && fb < fm) ? pb : none);
       if (fm == 4) spr_scale_cells<T, V, 4>(x, xsn, xsh, xsw, y, ysn, ysh, ysw, att, n, H, W, C, big, small);
       else spr_scale_cells<T, V, 2>(x, xsn, xsh, xsw, y, ysn, ysh, ysw, att, n, H, W, C, big, small);
+      fin();
       return;
     }
   }
@@ -501,6 +635,7 @@ __global__ __launch_bounds__(256) void spr_attn_scale_kernel(const float* __rest
       stv<T, V>((T*)P.y + n * P.sn + oy * P.sh + ox * P.sw + q * V, acc);
     }
   }
+  fin();
 }
 
 extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tiles_x, int tiles_y, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int groups,
@@ -514,7 +649,11 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tile
   if (!vec4_ok(x, dtype) || !vec4_ok(y, dtype) || x->n != y->n || x->h != y->h || x->w != y->w || y->c != c)
     MGDT_FAIL(MGDT_BAD_SHAPE, "spr_attn_scale: views must be matching NHWC, c%%4==0");
   const int cw = c / groups, hid = cw / 4;
-  const size_t lds = (size_t)(c * 5 + groups * hid + 2 * c) * sizeof(float);
+  size_t lds = (size_t)(c * 5 + groups * hid + 2 * c) * sizeof(float);
+  const size_t wbytes = ((size_t)hid * (5 * cw + 4) + (size_t)cw * (hid + 1) + hid + cw + 4) * sizeof(float);
+  // the latency-lean prologue: per-tile sums, one pass over the channels, fc weights staged in LDS (cw <= 80); anything else takes the general one
+  const int fast = tiles_x > 0 && c <= 256 && lds + wbytes <= 48 * 1024 && ((uintptr_t)fc1_w & 15) == 0;
+  if (fast) lds += wbytes;
   SprPool pl[2] = {{nullptr, 0, 0, 0, 0}, {nullptr, 0, 0, 0, 0}};
   bool pool8 = true;
   const mgdt_view* pv[2] = {pool_a, pool_b};
@@ -526,17 +665,35 @@ extern "C" int mgdt_spr_attn_scale_fwd(const float* pooled, int nsplit, int tile
     pl[i].y = p->p; pl[i].sn = p->sn; pl[i].sh = p->sh; pl[i].sw = p->sw; pl[i].F = x->h / p->h;
     pool8 = pool8 && vecN_ok(p, dtype, 8);
   }
+  static unsigned long long* dbgbuf = nullptr;      // MGDT_SPR_DBG: per workgroup {start, attention weights ready, end} in 10 ns ticks
+  if (getenv("MGDT_SPR_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 4096 * 8 * 8);
+  int gK = 0;
   MGDT_DISPATCH_TV(dtype, vecN_ok(x, dtype, 8) && vecN_ok(y, dtype, 8) && pool8, {
     const long vecs = (long)x->h * x->w * (c / V);
     static const long per_wg = getenv("MGDT_SPR_VECS") ? atol(getenv("MGDT_SPR_VECS")) : 2048;   // experiment knob: vectors per workgroup
     // every workgroup repeats the attention prologue (the reduction of the per-tile sums dominates it): ~12 workgroups per image measured best on all
     // four backbone levels (33.5 / 21.0 / 17.2 / 20.6 us vs 41.9 / 23.2 / 17.2 / 20.6 with up to 64)
-    const int K = (int)std::max<long>(1, std::min<long>(12, vecs / per_wg));
+    static const long kmax = getenv("MGDT_SPR_KMAX") ? atol(getenv("MGDT_SPR_KMAX")) : 12;
+    const int K = (int)std::max<long>(1, std::min<long>(kmax, vecs / per_wg));
     spr_attn_scale_kernel<T, V><<<dim3(K, x->n), 256, lds, (hipStream_t)s>>>(pooled, fc1_w, fc1_b, fc2_w, fc2_b, c, groups, x->h, x->w, (const T*)x->p, x->sn,
                                                                               x->sh, x->sw, (T*)y->p, y->sn, y->sh, y->sw, make_fastdiv((uint32_t)(c / V)),
-                                                                              make_fastdiv((uint32_t)x->w), nsplit, tiles_x, tiles_y, pl[0], pl[1]);
+                                                                              make_fastdiv((uint32_t)x->w), nsplit, tiles_x, tiles_y, pl[0], pl[1],
+                                                                              make_fastdiv((uint32_t)(tiles_x > 0 ? nsplit / (tiles_x * tiles_y) : 1)),
+                                                                              make_fastdiv((uint32_t)std::max(tiles_x, 1)), make_fastdiv((uint32_t)(5 * cw / 4)), fast, dbgbuf);
+    gK = K;
   });
   MGDT_CHECK_LAUNCH("spr_attn_scale_fwd");
+  if (dbgbuf && gK * x->n <= 4096) {
+    (void)hipStreamSynchronize((hipStream_t)s);
+    std::vector<unsigned long long> h((size_t)gK * x->n * 8);
+    (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0; double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int ns = fast ? 8 : 3;
+    for (int i = 0; i < gK * x->n; ++i) { t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + ns - 1]); for (int k = 0; k + 1 < ns; ++k) ph[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]); }
+    fprintf(stderr, "spr_attn_scale c %d %dx%d: %d wgs, span %.1f us; mean per wg (us):", c, x->h, x->w, gK * x->n, (t1 - t0) * 0.01);
+    for (int k = 0; k + 1 < ns; ++k) fprintf(stderr, " %.2f", ph[k] * 0.01 / (gK * x->n));
+    fprintf(stderr, fast ? "  (issue | loads land | sums | fc1 | fc2 | softmax | scale)\n" : "  (prologue | scale)\n");
+  }
   return MGDT_OK;
 }
 

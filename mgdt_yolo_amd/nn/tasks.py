@@ -91,23 +91,80 @@ class BaseModel(nn.Module):
         plan = self._neck_plan(x) if not self.training else None
         bufs = {}                                           # consumer layer -> {'out': concat buffer, 'done': slots, 'pooled0': ...}
         head = None                                         # (injection module, its inputs) waiting for the C2f block behind it
-        for m in layers:
-            if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+        side = self._side_branch() if not self.training else None
+        first = layers[0].i
+        y += [None] * (len(self.model) - len(y))
+        prev = {first - 1: x}                               # outputs waiting for the layer behind them (f = -1)
+
+        def run(m):
+            nonlocal head
+            src = lambda j: prev[m.i - 1] if j == -1 else y[m.i + j if j < 0 else j]
+            xin = src(m.f) if isinstance(m.f, int) else [src(j) for j in m.f]
             if head is not None:                            # the injection in front of this C2f runs inside this block's first launch
-                x, head = m(None, head=head), None
+                out, head = m(None, head=head), None
             elif self._injection_feeds_next(m):
-                head = (m, x)
-                y.append(None)
-                continue
+                head, out = (m, xin), None
             elif plan is not None and m.i in plan['producers']:
-                x = m(x, deliver=self._neck_deliveries(plan, m, x, bufs))
+                out = m(xin, deliver=self._neck_deliveries(plan, m, xin, bufs))
             elif plan is not None and m.i in plan['consumers']:
-                x = m(x, pre=bufs.get(m.i))
+                out = m(xin, pre=bufs.get(m.i))
             else:
-                x = m(x)
-            y.append(x if m.i in self.save else None)
-        return x
+                out = m(xin)
+            prev.pop(m.i - 1, None)
+            prev[m.i] = out
+            y[m.i] = out if m.i in self.save else None
+
+        if side is None or side[2] < first:
+            for m in layers:
+                run(m)
+            return prev[len(self.model) - 1]
+        s0, s1, dep = side
+        main, other = torch.cuda.current_stream(), ops.side_stream(x.device)
+        for m in layers:
+            if s0 <= m.i <= s1:
+                continue                                    # ran on the side stream, right behind layer `dep`
+            if m.i == s1 + 1:
+                main.wait_stream(other)
+            run(m)
+            if m.i == dep:
+                other.wait_stream(main)
+                with torch.cuda.stream(other):
+                    for k in range(s0, s1 + 1):
+                        run(self.model[k])
+        if s1 + 1 >= len(self.model):
+            main.wait_stream(other)
+        return prev[len(self.model) - 1]
+
+    def _side_branch(self):
+        """(first, last, dep): layers first..last read nothing newer than layer `dep` < first - 1, i.e. they do not depend on layers dep+1 ..
+        first-1 and can run beside them.  In the MSPA-GD graphs that is the high-level branch's local input (Conv on P4 + SimFusion_3in: four
+        launches that fill a quarter of the chip each) next to the end of the backbone, the low-level SimFusion_4in and the IFM: they go to a second
+        HIP stream right behind layer `dep` (a parallel branch of the captured graph) and are joined in front of layer last+1.  Static per
+        model; None when the layer list has no such run, when hooks watch the layers, or when ops.SIDE_STREAM is off."""
+        if not ops.SIDE_STREAM:
+            return None
+        if '_side_branch_cache' not in self.__dict__:
+            absf = lambda m: [m.i + f if f < 0 else f for f in ([m.f] if isinstance(m.f, int) else m.f)]
+            best = None
+            n = len(self.model)
+            for s0 in range(2, n - 1):
+                deps, s1 = set(), s0 - 1
+                for k in range(s0, n - 1):                   # the last layer (the head) stays on the main stream
+                    ext = {j for j in absf(self.model[k]) if j < s0}
+                    if ext and max(ext) >= s0 - 1:
+                        break
+                    deps |= ext
+                    s1 = k
+                if s1 < s0 or not deps:
+                    continue
+                dep = max(deps)
+                if best is None or (s0 - 1 - dep, s1 - s0) > (best[0] - 1 - best[2], best[1] - best[0]):
+                    best = (s0, s1, dep)
+            self.__dict__['_side_branch_cache'] = best
+        best = self.__dict__['_side_branch_cache']
+        if best is None or any(self.model[k]._forward_hooks for k in range(best[2] + 1, best[1] + 1)):
+            return None
+        return best
 
     def _injection_feeds_next(self, m):
         """layer m is an InjectionMultiSum_Auto_pool whose only consumer is the C2f right behind it (bf16 inference, no hooks): the pair runs

@@ -5,6 +5,7 @@ Activations are torch tensors shaped (B, C, H, W) in channels_last memory format
 slices `t[:, a:b]` are passed as strided views - the reference's chunk()/split()/cat() never copy here.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -64,6 +65,18 @@ class profile:
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+SIDE_STREAM = os.environ.get('MGDT_SIDE_STREAM', '1') != '0'      # inference: layers that do not depend on their predecessors run on a second HIP stream (BaseModel._side_branch)
+_SIDE = {}
+
+
+def side_stream(device):
+    """The second launch stream of `device` (one per process and device; created outside graph capture on first use)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
 
 
 _FORCE_CTX = [0]
@@ -517,7 +530,23 @@ def cnx_mlp(t, res, pk, gamma, beta, out=None):
 
 FUSED_CNX_BLOCK = True  # tests flip this to compare against dwconv7_ln + the two-pass MLP
 FUSED_CNX_TAIL = True   # ... and the IFM's closing 1x1 conv inside the last block's launch vs a launch of its own
-_CNX_WS = {}            # (device, shape) -> zero-initialised workspace of mgdt_cnx_block_fwd (its barrier words live across calls)
+_CNX_WS = {}            # (device, shape, lane) -> zero-initialised workspace of mgdt_cnx_block_fwd (its barrier words live across calls)
+_LANE = [0]
+
+
+class lane:
+    """with ops.lane(i): forwards whose launches may run CONCURRENTLY with those of another lane (several captured graph instances replayed on
+    different streams) - kernels that keep state in a cached workspace (the block barrier of mgdt_cnx_block_fwd) get one workspace per lane."""
+
+    def __init__(self, i):
+        self.i = int(i)
+
+    def __enter__(self):
+        self.prev, _LANE[0] = _LANE[0], self.i
+
+    def __exit__(self, *exc):
+        _LANE[0] = self.prev
+        return False
 
 
 def cnx_block_supported(x, dtype):
@@ -534,7 +563,7 @@ def cnx_block(x, dw_w49c, dw_b, ln_w, ln_b, eps, pk, gamma, beta, out=None, tail
     if out.data_ptr() == x.data_ptr():
         raise RuntimeError('cnx_block: the output may not alias the input (tiles read their neighbours\' halo)')
     nbytes = L.lib().mgdt_cnx_block_workspace_bytes(b, h, w, c)
-    key = (x.device, b, c, h, w)
+    key = (x.device, b, c, h, w, _LANE[0])
     ws = _CNX_WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():

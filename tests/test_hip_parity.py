@@ -1358,6 +1358,54 @@ def test_neck_inputs_delivered_by_their_producers(shape):
         assert saved == 5 and n1.count('adaptive_avgpool_fwd') == 0 and n1.count('copy_fwd') == 0, (saved, n1)
 
 
+@pytest.mark.parametrize('name,dtype', [('mspa_c2f_gd_yolov8', torch.bfloat16), ('mspa_c2f_gd_yolov8', torch.float32), ('mspa_c2f_gd_tood_yolov8', torch.bfloat16)])
+def test_side_stream_branch_is_the_same_forward(name, dtype):
+    """Layers 12-13 (Conv on P4 + SimFusion_3in: the high-level branch's local input) do not depend on layers 7-11 (end of the backbone,
+    SimFusion_4in, IFM): BaseModel._side_branch sends them to a second HIP stream right behind layer 6.  Same kernels, same inputs: the
+    outputs must be IDENTICAL to the single-stream forward, eagerly and as a captured graph with a parallel branch (replayed on changing
+    input).  Stock yolov8 has no such run of layers and stays on one stream."""
+    from mgdt_yolo_amd import ops
+    m = build_model(name, dtype)
+    assert m._side_branch() == (12, 13, 6) and build_model('yolov8')._side_branch() is None
+    xs = [seeded_images(2, 320, 256, seed=s).to(DEV).to(dtype) for s in (3, 4)]
+    with torch.no_grad():
+        ops.SIDE_STREAM = False
+        try:
+            ref = [[t.clone() for t in _flat(m(x))] for x in xs]
+        finally:
+            ops.SIDE_STREAM = True
+        streams = []
+        orig = ops._launch
+        ops._launch = lambda nm, *a, **k: (streams.append(torch.cuda.current_stream().cuda_stream), orig(nm, *a, **k))[1]
+        try:
+            got = _flat(m(xs[0]))
+        finally:
+            ops._launch = orig
+        assert len(set(streams)) == 2, 'the branch was not launched on a second stream'
+        assert all(torch.equal(a, b) for a, b in zip(got, ref[0]))
+        # captured: the branch becomes a parallel path of the graph
+        xin = xs[0].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(xin)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = _flat(m(xin))
+        for x, r in zip(xs[::-1], ref[::-1]):
+            xin.copy_(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(out, r))
+
+
+def _flat(o):
+    if torch.is_tensor(o):
+        return [o]
+    return [t for e in o for t in _flat(e)]
+
+
 def test_e2e_bf16_fused_kernels_vs_launch_chains_at_bench_shape():
     """The bench configuration (B=8 of the 32, 640x640, bf16) with every fused kernel of this round switched off (conv / GRN / inject launch
     chains) vs on: same model, same input.  Differences are bf16 re-association only; both variants are bf16 forwards, each within the
