@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer')
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--imgsz', type=int, default=640)
-    ap.add_argument('--inflight', type=int, default=1, help='(experimental, refuses to print a value) S hipGraphs replayed concurrently on S streams')
+    ap.add_argument('--inflight', type=int, default=None, help='S batches in flight: the resident batches\' graphs are replayed round-robin on S streams (inference; results are checked against serial replay)')
     ap.add_argument('--input', choices=['model', 'f32', 'u8'], default='model',
                     help="dtype of the resident image batch: 'model' = the compute dtype, what the reference's predictor hands its model "
                          "(img.half() / 255, engine/predictor.py:128-129); 'u8' = raw uint8, /255 fused into the stem kernel")
@@ -225,10 +225,10 @@ def roofline_of(prof_rows, reps, step_ms, graph, args):
 
 def main():
     args = parse()
-    if args.inflight > 1:
-        # concurrent replay of several graph instances gave wrong results on this stack (tools/graph_min.py); until that is
-        # root-caused no throughput number may come out of it
-        raise SystemExit('bench.py: --inflight > 1 is disabled (concurrent hipGraph replay is not verified correct); it never feeds `value`')
+    if args.inflight is None:        # default: 4 batches in flight for the captured inference step (each step is still one whole batch: forward + NMS)
+        args.inflight = 4 if (args.mode == 'infer' and not args.no_graph) else 1
+    if args.inflight > 1 and (args.mode != 'infer' or args.no_graph):
+        raise SystemExit('bench.py: --inflight applies to the captured inference step only')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args))
 
@@ -318,6 +318,7 @@ def main():
         def step_eager():
             return step(xs[0])
 
+        S = max(1, min(args.inflight, R))                 # lanes: graph r belongs to lane r % S; the lanes' replays run concurrently on S streams
         with torch.no_grad():
             out = step(xs[0])                       # packs the weights, allocates
             torch.cuda.synchronize()
@@ -326,21 +327,46 @@ def main():
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    for _ in range(2):
-                        out = step(xs[0])
+                    for j in range(S):              # per-lane state (the block barrier words of mgdt_cnx_block_fwd) is created outside capture
+                        with ops.lane(j):
+                            for _ in range(2):
+                                out = step(xs[0])
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                pool = torch.cuda.graph_pool_handle()      # the R graphs replay one after the other: they share one activation pool
+                # one lane (serial replay): the R graphs share one activation pool.  Several lanes: every graph owns its pool - graphs that share
+                # one may only replay in capture order, and a graph captured earlier reuses, as scratch, the memory that holds a later graph's
+                # outputs (the results are compared after the timed loop, whatever graph ran last)
+                pools = [torch.cuda.graph_pool_handle() for _ in range(R if S > 1 else 1)]
                 for r in range(R):
                     g = torch.cuda.CUDAGraph()
                     # several ranks: RCCL's watchdog thread may poll events while this thread captures - keep the capture's error mode thread-local
-                    with torch.cuda.graph(g, pool=pool, **({'capture_error_mode': 'thread_local'} if world > 1 else {})):
+                    with ops.lane(r % S), torch.cuda.graph(g, pool=pools[r % len(pools)], **({'capture_error_mode': 'thread_local'} if world > 1 else {})):
                         outs.append(step(xs[r]))
                     graphs.append(g)
                 out = outs[-1]
                 graph_used = True
         it = [0]
-        if graph_used:
+        lanes = [torch.cuda.Stream() for _ in range(S)] if (graph_used and S > 1) else []
+        serial_ref = None
+        if lanes:
+            # what every graph must produce: its own serial replay (counts, detections and kept anchors of the valid rows)
+            def snapshot():
+                res = []
+                for o in outs:
+                    valid = torch.arange(o[1].shape[1], device=dev)[None, :] < o[2][:, None]
+                    res.append((o[2].clone(), o[0][valid].clone(), o[1][valid].clone()))
+                return res
+            for g in graphs:
+                g.replay()
+            torch.cuda.synchronize()
+            serial_ref = snapshot()
+
+            def run():
+                r = it[0] % R
+                with torch.cuda.stream(lanes[r % S]):
+                    graphs[r].replay()
+                it[0] += 1
+        elif graph_used:
             def run():
                 graphs[it[0] % R].replay()
                 it[0] += 1
@@ -352,21 +378,48 @@ def main():
                 it[0] += 1
         x_desc = f'{str(xs[0].dtype).replace("torch.", "")} NCHW images, {R} different batches resident in HBM ({R * xs[0].numel() * xs[0].element_size() / 2**20:.0f} MiB) cycled'
         workload = (f'{args.model}-{args.scale} (MSPA-C2f + GD neck + Detect, nc=80) {args.imgsz}x{args.imgsz} inference, batch {args.batch}/GPU: '
-                    f'forward + decode + NMS(conf 0.25, iou 0.7), ' + ('hipGraph replay' if graph_used else 'eager launches') + fp8_note)
+                    f'forward + decode + NMS(conf 0.25, iou 0.7), ' + ('hipGraph replay' if graph_used else 'eager launches')
+                    + (f', {S} batches in flight (one captured graph per resident batch, replayed round-robin on {S} streams)' if lanes else '') + fp8_note)
         metric = f'images/sec @{args.imgsz}x{args.imgsz} bs={args.batch} per GPU, detection forward + NMS (whole job: {world} GPU(s))'
         parallelism = f'replicas x{world} (batch-sharded, no data-path collective)'
 
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = parallel.max_over_ranks(t1 - t0, dev)
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        return parallel.max_over_ranks(t1 - t0, dev)
+
+    elapsed = timed(run)
+    serial_ms = None
     if args.mode == 'infer':
+        if serial_ref is not None:
+            # the overlapped replays must have produced exactly what the serial replays did; if they did not (never observed since the library is
+            # built without packed-fp32 VALU ops, profiles/r03_graph_replay_root_cause.txt) the number is thrown away and the serial replay is timed
+            bad = [r for r, (got, ref) in enumerate(zip(snapshot(), serial_ref)) if not all(torch.equal(a, b) for a, b in zip(got, ref))]
+            bad = int(parallel.max_over_ranks(float(len(bad)), dev))
+
+            def run_serial():
+                graphs[it[0] % R].replay()
+                it[0] += 1
+            if bad:
+                print(f'bench.py: {bad} batch(es) differ between concurrent and serial replay - timing the serial replay instead', file=sys.stderr)
+                workload = workload.replace(f', {S} batches in flight (one captured graph per resident batch, replayed round-robin on {S} streams)', '')
+                lanes, S = [], 1
+                elapsed = timed(run_serial)
+            else:                               # one batch at a time, for the latency side of the trade
+                it[0] = 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2 * R):
+                    run_serial()
+                torch.cuda.synchronize()
+                serial_ms = (time.perf_counter() - t0) / (2 * R) * 1e3
         n_det = int(out[2].sum().item())
 
     # ---- roofline of the dominant kernel: eager launches bracketed by HIP events on the launch stream
@@ -387,7 +440,8 @@ def main():
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': workload, 'global_batch': world * args.batch, 'parallelism': parallelism, 'rccl_ranks': world,
                            'input': x_desc, 'detections_last_step': n_det, 'weights': 'seeded random init (no checkpoints offline)',
-                           'timed_region_s': round(elapsed, 3)},
+                           'timed_region_s': round(elapsed, 3), 'batches_in_flight': (S if args.mode == 'infer' and graph_used else 1),
+                           'ms_per_step_one_batch_at_a_time': (round(serial_ms, 4) if serial_ms else None)},
                 'roofline': roof}
         # whole-step fractions against SURVEY 8(d)'s layer-level algorithmic work per image (each top-level layer reads its inputs and writes
         # its output once, weights amortised; 2*MAC over every conv / linear): the distance of the WHOLE step - not of one kernel - from the chip

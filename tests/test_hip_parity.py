@@ -1400,6 +1400,52 @@ def test_side_stream_branch_is_the_same_forward(name, dtype):
             assert all(torch.equal(a, b) for a, b in zip(out, r))
 
 
+def test_graph_instances_in_flight_match_their_serial_replays():
+    """bench.py --inflight: several captured instances of the inference step (forward + NMS, each with its parallel branch) replayed
+    concurrently on their own streams.  Round 2 saw wrong values here (conv_igemm -> bilinear); the cause was packed-fp32 VALU arithmetic
+    beside another queue's MFMA kernel (profiles/r03_graph_replay_root_cause.txt), the library is built without it.  Every instance must
+    reproduce its serial replay bit for bit, over many overlapped rounds; ops.lane gives each instance its own block-barrier workspace."""
+    from mgdt_yolo_amd import ops
+    m = build_model('mspa_c2f_gd_yolov8', torch.bfloat16)
+    S = 3
+    xs = [seeded_images(4, 320, 320, seed=40 + j).to(DEV).to(torch.bfloat16) for j in range(S)]
+
+    def step(x):
+        y, _ = m(x)
+        return ops.nms(y, 0.05, 0.7, None, False, False, 300, 30000, 7680) + (y,)
+
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for j in range(S):
+                with ops.lane(j):
+                    step(xs[j])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs, outs = [], []
+        for j in range(S):
+            g = torch.cuda.CUDAGraph()
+            with ops.lane(j), torch.cuda.graph(g):
+                outs.append(step(xs[j]))
+            graphs.append(g)
+        refs = []
+        for j in range(S):
+            graphs[j].replay()
+            torch.cuda.synchronize()
+            refs.append([t.clone() for t in outs[j]])
+        assert not torch.equal(refs[0][3], refs[1][3]), 'the instances should see different images'
+        lanes = [torch.cuda.Stream() for _ in range(S)]
+        for rnd in range(40):
+            for j in range(S):
+                with torch.cuda.stream(lanes[j]):
+                    graphs[j].replay()
+            if rnd % 8 == 7:
+                torch.cuda.synchronize()
+                for j in range(S):
+                    assert all(torch.equal(a, b) for a, b in zip(outs[j], refs[j])), (rnd, j)
+
+
 def _flat(o):
     if torch.is_tensor(o):
         return [o]
