@@ -438,7 +438,7 @@ def main():
                     step(xs[0])
                     torch.cuda.synchronize()
                     g1 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1):
+                    with torch.cuda.graph(g1, **({'capture_error_mode': 'thread_local'} if world > 1 else {})):      # (RCCL's watchdog thread, as above)
                         o1 = step(xs[0])
                     for _ in range(3):
                         g1.replay()
