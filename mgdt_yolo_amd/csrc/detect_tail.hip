@@ -104,11 +104,11 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
       float den = 0.f, num = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float e = expf(lb[k] - mx);
-        den += e;
+        const float e = __builtin_amdgcn_exp2f((lb[k] - mx) * 1.4426950408889634f);     // hardware exp2 / rcp (~1 ulp each): libm's expf and the IEEE division
+        den += e;                                                                       // were half of this kernel's VALU instructions
         num += e * (float)k;
       }
-      const float dd = num / den;
+      const float dd = num * __builtin_amdgcn_rcpf(den);
       const float dl = __shfl(dd, r, 64), dt = __shfl(dd, 16 + r, 64), dr = __shfl(dd, 32 + r, 64), db = __shfl(dd, 48 + r, 64);
       const float ax = (float)ox + 0.5f, ay = (float)oy + 0.5f;            // make_anchors offset 0.5 (tal.py:476-488)
       const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;       // dist2bbox (tal.py:491-500), then * stride (head.py:176)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
         bstore4<bf16>(frs, c < a.nc ? (uint32_t)fo + (uint32_t)((r4 + c) * 2) : (uint32_t)MGDT_OOB, f32x4{lc[0], lc[1], lc[2], lc[3]});
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (c + j < a.nc) yt[(4 + c + j) * DT_LD + u * 16 + r] = 1.f / (1.f + expf(-lc[j]));
+          if (c + j < a.nc) yt[(4 + c + j) * DT_LD + u * 16 + r] = fast_sigmoid(lc[j]);
       }
     }
     // the wave's [4+nc][32] tile -> y rows (128-byte runs along the anchor axis); a wave's LDS accesses complete in order
