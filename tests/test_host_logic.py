@@ -61,6 +61,31 @@ def test_parse_reference_yaml_files():
     assert sum(p.numel() for p in s.parameters()) == 4149424
 
 
+def test_side_branch_plan_is_a_dependency_fact_of_the_layer_list():
+    """BaseModel._side_branch: the run of layers launched on the second stream must read nothing newer than `dep`, and every layer between
+    dep and the run must be independent of the run (they are earlier in the list).  MSPA-GD graphs: (12, 13, 6); stock yolov8: no such run;
+    hooks on the layers involved or ops.SIDE_STREAM = False switch it off."""
+    from mgdt_yolo_amd import ops
+    for name in ('mspa_c2f_gd_yolov8', 'mspa_c2f_gd_tood_yolov8'):
+        m = tasks.DetectionModel(get_config(name, 'n'), verbose=False)
+        s0, s1, dep = m._side_branch()
+        assert (s0, s1, dep) == (12, 13, 6)
+        absf = lambda l: [l.i + f if f < 0 else f for f in ([l.f] if isinstance(l.f, int) else l.f)]
+        ext = {j for k in range(s0, s1 + 1) for j in absf(m.model[k]) if j < s0}
+        assert ext and max(ext) == dep and dep < s0 - 1
+        assert any(j in range(s0, s1 + 1) for j in absf(m.model[s1 + 1])), 'the layer behind the run is its consumer (the join point)'
+        h = m.model[12].register_forward_hook(lambda *a: None)
+        assert m._side_branch() is None
+        h.remove()
+        assert m._side_branch() == (12, 13, 6)
+        ops.SIDE_STREAM = False
+        try:
+            assert m._side_branch() is None
+        finally:
+            ops.SIDE_STREAM = True
+    assert tasks.DetectionModel(get_config('yolov8', 'n'), verbose=False)._side_branch() is None
+
+
 def test_model_structure_and_state_dict_names():
     m = tasks.DetectionModel(get_config('yolov8', 'n'), verbose=False)
     assert sum(p.numel() for p in m.parameters()) == 2847732 and m.stride.tolist() == [8.0, 16.0, 32.0]   # SURVEY App. A.1
