@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmgdt_hip.so')
+LIB_PATH = os.environ.get('MGDT_LIB') or os.path.join(_HERE, 'csrc', 'libmgdt_hip.so')      # MGDT_LIB: another build of the same ABI (tools/graph_bisect3.py)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 1, 2, 3

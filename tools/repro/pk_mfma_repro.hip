@@ -71,8 +71,29 @@ __global__ __launch_bounds__(256) void mfma_kernel(float* out, int iters, const 
   *(bf16x4*)((bf16*)out + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = o;
 }
 
+// the plain form: nothing but MFMAs (the one that DOES disturb the packed-fp32 kernel inside tools/graph_bisect3.py)
+__global__ __launch_bounds__(256) void mfma_plain_kernel(bf16* out, int iters) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[k] = (bf16)(0.001f * (float)((threadIdx.x + k) & 15)); b[k] = (bf16)(0.002f * (float)((threadIdx.x * 3 + k) & 15)); }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  for (int i = 0; i < iters; ++i) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc3, 0, 0, 0);
+  }
+  const f32x4 s = acc0 + acc1 + acc2 + acc3;
+  typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)s[j];
+  *(bf16x4*)(out + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4) = o;
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 3000, mfma_wgs = argc > 2 ? atoi(argv[2]) : 256, mfma_iters = argc > 3 ? atoi(argv[3]) : 4000;
+  const bool plain = argc > 4 && atoi(argv[4]) != 0;     // graph instances: plain 300-iteration MFMA kernel (256 workgroups) in front of the interpolation
   const int N = 32, H = 20, W = 20, C = 128, Ho = 40, Wo = 40;
   const size_t nin = (size_t)N * H * W * C, nout = (size_t)N * Ho * Wo * C;
   std::vector<unsigned short> hx(nin);
@@ -114,10 +135,11 @@ int main(int argc, char** argv) {
     const int S = 5;
     std::vector<hipStream_t> st(S); std::vector<hipGraphExec_t> ge(S); std::vector<bf16*> outb(S); std::vector<float*> mb(S);
     for (int j = 0; j < S; ++j) {
-      CK(hipStreamCreate(&st[j])); CK(hipMalloc(&outb[j], nout * 2)); CK(hipMalloc(&mb[j], (size_t)mfma_wgs * 256 * 8));
+      CK(hipStreamCreate(&st[j])); CK(hipMalloc(&outb[j], nout * 2)); CK(hipMalloc(&mb[j], (size_t)(mfma_wgs > 256 ? mfma_wgs : 256) * 256 * 8));
       hipGraph_t g;
       CK(hipStreamBeginCapture(st[j], hipStreamCaptureModeThreadLocal));
-      mfma_kernel<<<mfma_wgs, 256, 64 * 1024, st[j]>>>(mb[j], mfma_iters / 4, dx, (unsigned)(nin * 2));
+      if (plain) mfma_plain_kernel<<<256, 256, 0, st[j]>>>((bf16*)mb[j], 300);
+      else mfma_kernel<<<mfma_wgs, 256, 64 * 1024, st[j]>>>(mb[j], mfma_iters / 4, dx, (unsigned)(nin * 2));
       lerp_kernel<<<6400, 256, 0, st[j]>>>(dx, outb[j], H, W, C, Ho, Wo, total);
       CK(hipStreamEndCapture(st[j], &g));
       CK(hipGraphInstantiate(&ge[j], g, nullptr, nullptr, 0));
@@ -125,8 +147,8 @@ int main(int argc, char** argv) {
     long gbad = 0, gbad_launch = 0, godd = 0, ghi = 0;
     const int grounds = rounds / 10;
     for (int r = 0; r < grounds; ++r) {
-      for (int j = 0; j < S; ++j) CK(hipMemsetAsync(outb[j], 0, nout * 2, st[j]));
-      for (int j = 0; j < S; ++j) CK(hipGraphLaunch(ge[j], st[j]));
+      for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < S; ++j) CK(hipGraphLaunch(ge[j], st[j]));
       CK(hipDeviceSynchronize());
       for (int j = 0; j < S; ++j) {
         CK(hipMemcpy(got.data(), outb[j], nout * 2, hipMemcpyDeviceToHost));
