@@ -72,10 +72,11 @@ _SIDE = {}
 
 
 def side_stream(device):
-    """The second launch stream of `device` (one per process and device; created outside graph capture on first use)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """The second launch stream of `device` (one per process, device and lane - see ops.lane; created outside graph capture on first use)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, _LANE[0])
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key)
+        _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
 
 
