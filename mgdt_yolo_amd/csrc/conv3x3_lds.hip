@@ -48,40 +48,46 @@ template <int ACT> __device__ __forceinline__ float c3_act(float v) {
 // S = 2 (round 2): the stride-2 down-sampling convolutions (32 -> 64 at 320 -> 160 .. 64 -> 128 at 80 -> 40).  Same structure; the region of a TH x 16 output
 // tile is (2 TH + 1) x 33 input pixels, lane r's pixel sits 2 r columns into its region row, and the cout blocks may be split over `ncg` workgroup groups
 // (each stages the region itself: 2 re-reads instead of the igemm kernel's 9 taps x cout groups through the texture path).
-template <int NBW, int ACT, int NCH, int MT, bool Q8 = false, int S = 1>
-__global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
+// WS = 2 (round 3): eight waves - waves 0-3 and 4-7 take the same pixel rows and each HALF of the cout blocks, so two waves per SIMD share the panel and the
+// region: one's LDS reads and epilogue run under the other's MFMAs (a single wave per SIMD had nothing to hide them behind), registers per wave halve
+template <int NBW, int ACT, int NCH, int MT, bool Q8 = false, int S = 1, int WS = 1>
+__global__ __launch_bounds__(256 * WS, 1) void conv3x3_lds_kernel(const C3Args a) {
+  constexpr int NTHR = 256 * WS, NBH = (NBW + WS - 1) / WS;                                // threads, cout blocks per wave (an odd count: the second group's last block is
+                                                                                            // a phantom - it multiplies whatever follows the panel and is never stored)
   constexpr int RW = 15 * S + 3, TH = 4 * MT, RH = (TH - 1) * S + 3, RPX = RH * RW;     // region width, tile rows, region rows, region pixels
-  constexpr int MAXI = S == 1 ? C3_MAXI : 18;
+  constexpr int MAXI = ((S == 1 ? C3_MAXI : 18) + WS - 1) / WS;
   constexpr int WB = Q8 ? 512 : 1024, PB = Q8 ? 8 : 16;         // bytes of a weight block / of an 8-channel piece in LDS
   extern __shared__ __attribute__((aligned(16))) char c3_lds[];
   int* tab = (int*)c3_lds;                                          // [nchunks * 4] byte offset of piece p inside the region, relative to the pixel's row
   char* wl = c3_lds + (((size_t)a.nchunks * 16 + 15) & ~(size_t)15);
   char* xs = wl + (size_t)a.nchunks * NBW * WB;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all & 3, wcol = wave_all >> 2;                 // pixel rows of the tile, cout half
   const int cg = blockIdx.x % a.ncg, w0 = blockIdx.x / a.ncg, wstep = gridDim.x / a.ncg;      // cout group, first tile, tile step of this workgroup
   const int nb0 = cg * NBW;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
 
   // ---- once per workgroup: piece table and the weight panel of its cout blocks
-  for (int p = tid; p < a.nchunks * 4; p += 256) {
+  for (int p = tid; p < a.nchunks * 4; p += NTHR) {
     const int tap = (int)fdiv((uint32_t)p, a.fd_cp), cp = p - tap * a.CP;
     tab[p] = tap < 9 ? ((tap / 3) * RW + (tap % 3)) * a.XP + cp * PB : 0;       // padding pieces carry zero weights: any in-range address
   }
   constexpr int WV = WB / 16;                                       // 16-byte vectors per weight block
-  for (int i = tid; i < a.nchunks * NBW * WV; i += 256) {
+  for (int i = tid; i < a.nchunks * NBW * WV; i += NTHR) {
     const int kc = i / (NBW * WV), rem = i - kc * NBW * WV, bw = rem / WV, ln = rem % WV;
     const bool ok = nb0 + bw < a.NTtot;
     const uint4 v = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * WV + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
     *(uint4*)(wl + (size_t)i * 16) = v;
   }
-  f32x4 bias[NBW], osc[Q8 ? NBW : 1];
+  const int nbw0 = nb0 + wcol * NBH;                                 // this wave's first cout block
+  f32x4 bias[NBH], osc[Q8 ? NBH : 1];
 #pragma unroll
-  for (int bw = 0; bw < NBW; ++bw) {
-    bias[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nb0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int bw = 0; bw < NBH; ++bw) {
+    bias[bw] = nbw0 + bw < a.NTtot ? *(const f32x4*)(a.bias + (nbw0 + bw) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (Q8) {                                              // accumulators start from bias / oscale, the epilogue multiplies by oscale
-      osc[bw] = nb0 + bw < a.NTtot ? *(const f32x4*)(a.oscale + (nb0 + bw) * 16 + 4 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
+      osc[bw] = nbw0 + bw < a.NTtot ? *(const f32x4*)(a.oscale + (nbw0 + bw) * 16 + 4 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
       bias[bw] = bias[bw] / osc[bw];
     }
   }
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
     const int iy0 = tyi * TH * S - 1, ix0 = txi * C3_TW * S - 1;
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
-      const int it = tid + u * 256;
+      const int it = tid + u * NTHR;
       const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
       const int py = pix / RW, px = pix - py * RW;
       const int iy = iy0 + py, ix = ix0 + px;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
   auto commit = [&]() {
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
-      const int it = tid + u * 256;
+      const int it = tid + u * NTHR;
       if (it < nitems) {
         const int pix = (int)fdiv((uint32_t)it, a.fd_cp), c8 = it - pix * a.CP;
         if constexpr (Q8) *(long*)(xs + pix * a.XP + c8 * 8) = quant8(__builtin_bit_cast(bf16x8, stage[u]), a.xq);
@@ -135,17 +141,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
     const int tn = t + wstep;
     if (tn < a.ntiles) issue(tn);                                    // in flight under this tile's MFMAs
 
-    f32x4 acc[NBW][MT];
+    f32x4 acc[NBH][MT];
 #pragma unroll
-    for (int bw = 0; bw < NBW; ++bw)
+    for (int bw = 0; bw < NBH; ++bw)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[bw][m] = bias[bw];
     typedef typename std::conditional<Q8, long, bf16x8>::type frag_t;
-    frag_t A[2][NBW], B[2][MT];
+    frag_t A[2][NBH], B[2][MT];
     auto load_frags = [&](int kc, int buf) {
       const int off = tab[kc * 4 + g];
 #pragma unroll
-      for (int bw = 0; bw < NBW; ++bw) A[buf][bw] = *(const frag_t*)(wlane + (size_t)(kc * NBW + bw) * WB);
+      for (int bw = 0; bw < NBH; ++bw) A[buf][bw] = *(const frag_t*)(wlane + (size_t)(kc * NBW + wcol * NBH + bw) * WB);
 #pragma unroll
       for (int m = 0; m < MT; ++m) B[buf][m] = *(const frag_t*)(xs + bbase[m] + off);
     };
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
       for (int kc = 0; kc < NCH; ++kc) {
         if (kc + 1 < NCH) load_frags(kc + 1, (kc + 1) & 1);
 #pragma unroll
-        for (int bw = 0; bw < NBW; ++bw)
+        for (int bw = 0; bw < NBH; ++bw)
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[kc & 1][bw], B[kc & 1][m], acc[bw][m]);
       }
@@ -167,13 +173,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
       for (int kc = 0; kc < a.nchunks; kc += 2) {
         if (kc + 1 < a.nchunks) load_frags(kc + 1, 1);
 #pragma unroll
-        for (int bw = 0; bw < NBW; ++bw)
+        for (int bw = 0; bw < NBH; ++bw)
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[0][bw], B[0][m], acc[bw][m]);
         if (kc + 1 < a.nchunks) {
           if (kc + 2 < a.nchunks) load_frags(kc + 2, 0);
 #pragma unroll
-          for (int bw = 0; bw < NBW; ++bw)
+          for (int bw = 0; bw < NBH; ++bw)
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[bw][m] = mm(A[1][bw], B[1][m], acc[bw][m]);
         }
@@ -191,8 +197,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_lds_kernel(const C3Args a) {
         const bool pin = oy < a.Ho && ox < a.Wo;
         const int po = n * a.ysn + oy * a.ysh + ox * a.ysw;
 #pragma unroll
-        for (int bw = 0; bw < NBW; ++bw) {
-          const int co = (nb0 + bw) * 16 + 4 * g;
+        for (int bw = 0; bw < NBH; ++bw) {
+          const int co = (nbw0 + bw) * 16 + 4 * g;
           bf16x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (bf16)c3_act<ACT>(Q8 ? acc[bw][m][j] * osc[Q8 ? bw : 0][j] : acc[bw][m][j]);
@@ -213,11 +219,13 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   const bool q8 = q8_oscale != nullptr;                    // e4m3 panel from mgdt_conv_pack_fp8
   static const int mode = getenv("MGDT_CONV3_LDS") ? atoi(getenv("MGDT_CONV3_LDS")) : 1;      // experiment knob: 0 = never
   if (!mode) return false;
+  static const bool ws2 = !(getenv("MGDT_C3_WAVES8") && atoi(getenv("MGDT_C3_WAVES8")) == 0);   // experiment knob: 0 = the four-wave form everywhere
+  const bool wide = mode >= 3 || ws2;     // the eight-wave forms also win where the four-wave ones lost to the igemm kernel: 64 -> 128 stride 2 (26.9 vs 30.6 us) and 80 -> 80 on 12x16 tiles (48.2 vs 50.9 us)
   const int Cin = x->c, Cout = y->c;
   // stride 2 - instantiated: bf16, 4 cout blocks per workgroup, Cin = 32 / 64.  Measured (B = 32, bench step): 32 -> 64 at 160 -> 80 35.9 us (igemm 38-40): default;
   // 64 -> 128 at 80 -> 40 35.4 us (igemm 34.9): only with MGDT_CONV3_LDS=3.  The 8x16-output tiles carry 72 / 144 MFMAs per wave, so a tile costs mostly its
   // staging latency and two barriers with one workgroup per CU - the LDS route wins much less here than the byte counts suggest.
-  if (stride == 2 && (q8_oscale || Cin > 64 || NTtot % 4 || (nchunks != 9 && !(nchunks == 18 && mode >= 3)))) return false;
+  if (stride == 2 && (q8_oscale || Cin > 64 || NTtot % 4 || (nchunks != 9 && !(nchunks == 18 && wide)))) return false;
   if (Cin % 8 || Cin < 32 || Cin > 80 || Cout % 4 || Cout < 32 || (act != MGDT_ACT_SILU && act != MGDT_ACT_NONE && act != MGDT_ACT_RELU)) return false;
   const long M = (long)x->n * x->h * x->w;
   if (M < 16 * 1024 || x->h < 16 || x->w < 16) return false;                                    // small maps: the igemm kernel's finer tiles fill the chip better
@@ -241,7 +249,7 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   const size_t fixed = (((size_t)nchunks * 16 + 15) & ~(size_t)15) + (size_t)nchunks * NBW * (q8 ? 512 : 1024);
   auto region = [&](int mt) { return stride == 2 ? (size_t)(8 * mt + 1) * 33 * a.XP : (size_t)(4 * mt + 2) * C3_RW * a.XP; };
   int MT = stride == 2 ? 2 : 4;                            // stride 1: 16x16 tiles when the region fits next to the panel, else 12x16 (5 cout blocks), else 8x16; stride 2: 8x16
-  if (stride == 1 && fixed + region(MT) > 160 * 1024) MT = NBW == 5 && !q8 && mode >= 3 && fixed + region(3) <= 160 * 1024 ? 3 : 2;   // 12x16 tiles at 80 -> 80: 58.9 us vs 55 us igemm
+  if (stride == 1 && fixed + region(MT) > 160 * 1024) MT = NBW == 5 && !q8 && wide && fixed + region(3) <= 160 * 1024 ? 3 : 2;   // 12x16 tiles at 80 -> 80: 58.9 us vs 55 us igemm
   const size_t lds = fixed + region(MT);
   if (lds > 160 * 1024) return false;
   if (NBW == 5 && !q8 && MT == 2 && mode < 2) return false;
@@ -273,30 +281,35 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
   }
 #define C3_ACT_Q8(NB) \
   if (act == MGDT_ACT_SILU) C3_LAUNCH_Q8(NB, MGDT_ACT_SILU) else if (act == MGDT_ACT_RELU) C3_LAUNCH_Q8(NB, MGDT_ACT_RELU) else C3_LAUNCH_Q8(NB, MGDT_ACT_NONE)
-#define C3_LAUNCH(NB, ACTV, MTV)                                                                                          \
+#define C3_LAUNCH(NB, ACTV, MTV, WSV)                                                                                     \
   {                                                                                                                  \
     static std::atomic<bool> attr{false}, attr18{false}, attr23{false};                                                                        \
     if (nchunks == 18) {                                                                                             \
-      if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
-      conv3x3_lds_kernel<NB, ACTV, 18, MTV><<<nwg, 256, lds, st>>>(a);                                                    \
+      if (!attr18) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 18, MTV, false, 1, WSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 18, MTV, false, 1, WSV><<<nwg, 256 * WSV, lds, st>>>(a);                                                    \
     } else if (nchunks == 23) {                                                                                      \
-      if (!attr23) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 23, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr23 = true; } \
-      conv3x3_lds_kernel<NB, ACTV, 23, MTV><<<nwg, 256, lds, st>>>(a);                                               \
+      if (!attr23) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 23, MTV, false, 1, WSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr23 = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 23, MTV, false, 1, WSV><<<nwg, 256 * WSV, lds, st>>>(a);                                               \
     } else {                                                                                                         \
-      if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0, MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-      conv3x3_lds_kernel<NB, ACTV, 0, MTV><<<nwg, 256, lds, st>>>(a);                                                     \
+      if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<NB, ACTV, 0, MTV, false, 1, WSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+      conv3x3_lds_kernel<NB, ACTV, 0, MTV, false, 1, WSV><<<nwg, 256 * WSV, lds, st>>>(a);                                                     \
     }                                                                                                                \
   }
-#define C3_ACT(NB, MTV) \
-  if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU, MTV) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU, MTV) else C3_LAUNCH(NB, MGDT_ACT_NONE, MTV)
+#define C3_ACT(NB, MTV, WSV) \
+  if (act == MGDT_ACT_SILU) C3_LAUNCH(NB, MGDT_ACT_SILU, MTV, WSV) else if (act == MGDT_ACT_RELU) C3_LAUNCH(NB, MGDT_ACT_RELU, MTV, WSV) else C3_LAUNCH(NB, MGDT_ACT_NONE, MTV, WSV)
   static unsigned long long* dbgbuf = nullptr;
   if (getenv("MGDT_C3_DBG") && !dbgbuf) (void)hipMalloc((void**)&dbgbuf, 256 * 6 * 8);   // nwg <= 256
   a.dbg = dbgbuf;
 #define C3_LAUNCH_S2(ACTV, NCHV)                                                                                      \
   {                                                                                                                  \
-    static std::atomic<bool> sattr{false};                                                                           \
-    if (!sattr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); sattr = true; } \
-    conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2><<<nwg, 256, lds, st>>>(a);                                          \
+    static std::atomic<bool> sattr{false}, sattr8{false};                                                            \
+    if (ws2) {                                                                                                       \
+      if (!sattr8) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); sattr8 = true; } \
+      conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2, 2><<<nwg, 512, lds, st>>>(a);                                   \
+    } else {                                                                                                         \
+      if (!sattr) { (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); sattr = true; } \
+      conv3x3_lds_kernel<4, ACTV, NCHV, 2, false, 2><<<nwg, 256, lds, st>>>(a);                                      \
+    }                                                                                                                \
   }
 #define C3_ACT_S2(NCHV) \
   if (act == MGDT_ACT_SILU) C3_LAUNCH_S2(MGDT_ACT_SILU, NCHV) else if (act == MGDT_ACT_RELU) C3_LAUNCH_S2(MGDT_ACT_RELU, NCHV) else C3_LAUNCH_S2(MGDT_ACT_NONE, NCHV)
@@ -304,7 +317,10 @@ bool mgdt_conv3x3_lds_launch(const mgdt_view* x, const mgdt_view* y, const void*
     if (nchunks == 9) { C3_ACT_S2(9) } else { C3_ACT_S2(18) }
   } else if (q8) {
     if (NBW == 6) { C3_ACT_Q8(6) } else if (NBW == 5) { C3_ACT_Q8(5) } else if (NBW == 4) { C3_ACT_Q8(4) } else if (NBW == 3) { C3_ACT_Q8(3) } else { C3_ACT_Q8(2) }
-  } else if (NBW == 6) { C3_ACT(6, 4) } else if (NBW == 5 && MT == 3) { C3_ACT(5, 3) } else if (NBW == 5) { C3_ACT(5, 2) } else if (NBW == 4) { C3_ACT(4, 4) } else if (NBW == 3) { C3_ACT(3, 4) } else { C3_ACT(2, 4) }
+  } else if (ws2 && (NBW == 6 || NBW == 4 || (NBW == 5 && MT == 3))) {
+    // eight waves, two per SIMD, each wave half the cout blocks
+    if (NBW == 6) { C3_ACT(6, 4, 2) } else if (NBW == 4) { C3_ACT(4, 4, 2) } else { C3_ACT(5, 3, 2) }
+  } else if (NBW == 6) { C3_ACT(6, 4, 1) } else if (NBW == 5 && MT == 3) { C3_ACT(5, 3, 1) } else if (NBW == 5) { C3_ACT(5, 2, 1) } else if (NBW == 4) { C3_ACT(4, 4, 1) } else if (NBW == 3) { C3_ACT(3, 4, 1) } else { C3_ACT(2, 4, 1) }
 #undef C3_ACT
 #undef C3_ACT_Q8
 #undef C3_ACT_S2
