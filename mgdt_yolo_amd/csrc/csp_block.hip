@@ -62,11 +62,8 @@ __device__ __forceinline__ f32x4 lds_load4(const char* p) {
 }
 
 // MODE 0 = MSPA_C2f, 1 = C2f.  WD = bottleneck width (8, 16, 32, 64).
-// NW = waves per workgroup: 8, or 16 (round 3) for the blocks whose LDS footprint leaves room for ONE workgroup per CU - the same tile, tables and LDS maps
-// worked by twice the waves (four per SIMD instead of two): every phase is a chain of LDS round trips per wave, more waves hide them behind each other
-template <int WD, int MODE, int NW = 8>
-__global__ __launch_bounds__(NW * 64, (NW == 16 ? 1 : ((WD <= 16 || (WD == 32 && MODE == 1)) ? 4 : 2))) void csp_block_kernel(const CspArgs a) {   // 4: two workgroups per CU (<= 128 VGPRs) where LDS allows it
-  constexpr int CSP_THREADS = NW * 64, CSP_NW = NW;         // (shadow the file-scope defaults)
+template <int WD, int MODE>
+__global__ __launch_bounds__(CSP_THREADS, ((WD <= 16 || (WD == 32 && MODE == 1)) ? 4 : 2)) void csp_block_kernel(const CspArgs a) {   // 4: two workgroups per CU (<= 128 VGPRs) where LDS allows it
   constexpr int CP = WD / 8;                         // 16-byte pieces per tap
   constexpr int NCHB = WD == 8 ? 2 : (WD == 16 ? 3 : (WD == 32 ? 5 : 8));   // K chunks of the back conv at n = 2 (concat <= 256 channels)
   constexpr int NB = WD >= 16 ? WD / 16 : 1;         // cout blocks of a wd -> wd conv
@@ -397,13 +394,7 @@ static bool csp_geometry(int mode, int H, int W, int wd, int nbtl, int catC, siz
 }
 
 static int csp_chain_nbk(int wd) { return wd >= 16 ? wd / 16 : 1; }
-static int csp_pool_gst(int cout, int nw) { const int nbo = (cout + 15) / 16; return (nbo < nw && nw % nbo == 0) ? nw / nbo : 1; }
-// waves per workgroup: 16 where the tile's LDS footprint allows one workgroup per CU only (MGDT_CSP_WAVES=8: always 8)
-static int csp_waves(int mode, const CspGeom& g) {
-  static const int forced = getenv("MGDT_CSP_WAVES") ? atoi(getenv("MGDT_CSP_WAVES")) : 0;
-  if (forced == 8 || forced == 16) return forced == 16 && mode == 0 ? 16 : 8;
-  return (mode == 0 && g.lds > 80 * 1024) ? 16 : 8;
-}
+static int csp_pool_gst(int cout) { const int nbo = (cout + 15) / 16; return (nbo < CSP_NW && CSP_NW % nbo == 0) ? CSP_NW / nbo : 1; }
 
 /* supported configurations of the fused block: bf16, wd in {8,16,32,64}, n in {1,2}; MSPA: even H, W; C2f: Cin % 32 == 0, Cin <= 256 */
 extern "C" int mgdt_csp_block_supported(int mode, int cin, int cout, int wd, int nbtl, int h, int w, int dtype) {
@@ -459,7 +450,7 @@ extern "C" int mgdt_csp_block_tiles(int mode, int n, int cin, int cout, int wd, 
     geom6[0] = g.TH; geom6[1] = g.TW; geom6[2] = g.RH; geom6[3] = g.RW; geom6[4] = (int)g.lds; geom6[5] = n * g.tiles_x * g.tiles_y;
     geom6[6] = g.tiles_x; geom6[7] = g.tiles_y;
   }
-  return g.tiles_x * g.tiles_y * csp_pool_gst(cout, csp_waves(mode, g));      // pool slots per image
+  return g.tiles_x * g.tiles_y * csp_pool_gst(cout);      // pool slots per image
 }
 
 extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* front, const float* front_bias, const void* const* mid,
@@ -491,7 +482,7 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   a.back = (const char*)back; a.back_bias = back_bias; a.pool = pool;
   a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = x->c; a.Cout = y->c; a.wd = wd; a.nbtl = nbtl; a.shortcut = shortcut; a.act = act;
   a.catC = (mode == 0 ? 3 : 2) * wd + nbtl * wd;
-  a.nchb = (a.catC / 8 + 3) / 4; a.nbo = (a.Cout + 15) / 16; 
+  a.nchb = (a.catC / 8 + 3) / 4; a.nbo = (a.Cout + 15) / 16; a.pool_gst = csp_pool_gst(a.Cout);
   const int nbk = csp_chain_nbk(wd);
   a.chain_words = mode == 0 ? 3 * ((nbk + 1) / 2) * nbk * 64 : 0;
   const size_t extra = mode == 0 ? (size_t)a.chain_words * 16 + 3 * nbk * 16 * 4 : 0;
@@ -499,8 +490,6 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   if (!csp_pick_tile(mode, a.H, a.W, a.N, wd, nbtl, a.catC, extra, &g)) MGDT_FAIL(MGDT_BAD_SHAPE, "csp_block: no tile fits %dx%d wd=%d n=%d", a.H, a.W, wd, nbtl);
   a.TH = g.TH; a.TW = g.TW; a.halo = g.halo; a.RH = g.RH; a.RW = g.RW; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   a.RPA = g.RPA; a.TPA = g.TPA; a.PS = g.PS; a.CS = g.CS;
-  const int nw = csp_waves(mode, g);
-  a.pool_gst = csp_pool_gst(a.Cout, nw);
   a.total_tiles = a.N * g.tiles_x * g.tiles_y;
   a.per_xcd = cdiv(a.total_tiles, 8);
   const int grid = 8 * a.per_xcd;
@@ -513,22 +502,20 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
     (void)hipMalloc((void**)&dbgbuf, dbgcap * 8);
   }
   a.dbg = getenv("MGDT_CSP_DBG") ? dbgbuf : nullptr;
-#define CSP_LAUNCH(WDV, MODEV, NWV)                                                                                         \
+#define CSP_LAUNCH(WDV, MODEV)                                                                                              \
   do {                                                                                                                      \
     static std::atomic<bool> attr{false};                                                                                            \
     if (!attr) {                                                                                                            \
-      hipError_t e_ = hipFuncSetAttribute((const void*)csp_block_kernel<WDV, MODEV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipError_t e_ = hipFuncSetAttribute((const void*)csp_block_kernel<WDV, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e_ != hipSuccess) MGDT_FAIL(MGDT_LAUNCH_FAIL, "csp_block: hipFuncSetAttribute: %s", hipGetErrorString(e_));         \
       attr = true;                                                                                                          \
     }                                                                                                                       \
-    csp_block_kernel<WDV, MODEV, NWV><<<grid, NWV * 64, g.lds, st>>>(a);                                                    \
+    csp_block_kernel<WDV, MODEV><<<grid, CSP_THREADS, g.lds, st>>>(a);                                                      \
   } while (0)
-  if (mode == 0 && nw == 16) {
-    switch (wd) { case 8: CSP_LAUNCH(8, 0, 16); break; case 16: CSP_LAUNCH(16, 0, 16); break; case 32: CSP_LAUNCH(32, 0, 16); break; default: CSP_LAUNCH(64, 0, 16); break; }
-  } else if (mode == 0) {
-    switch (wd) { case 8: CSP_LAUNCH(8, 0, 8); break; case 16: CSP_LAUNCH(16, 0, 8); break; case 32: CSP_LAUNCH(32, 0, 8); break; default: CSP_LAUNCH(64, 0, 8); break; }
+  if (mode == 0) {
+    switch (wd) { case 8: CSP_LAUNCH(8, 0); break; case 16: CSP_LAUNCH(16, 0); break; case 32: CSP_LAUNCH(32, 0); break; default: CSP_LAUNCH(64, 0); break; }
   } else {
-    switch (wd) { case 16: CSP_LAUNCH(16, 1, 8); break; case 32: CSP_LAUNCH(32, 1, 8); break; default: CSP_LAUNCH(64, 1, 8); break; }
+    switch (wd) { case 16: CSP_LAUNCH(16, 1); break; case 32: CSP_LAUNCH(32, 1); break; default: CSP_LAUNCH(64, 1); break; }
   }
 #undef CSP_LAUNCH
   MGDT_CHECK_LAUNCH("csp_block_fwd");

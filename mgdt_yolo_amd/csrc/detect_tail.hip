@@ -25,15 +25,16 @@ struct DtArgs {
 };
 
 constexpr int DT_THREADS = 256;
-constexpr int DT_LD = 33;               // row pitch (floats) of a wave's [4+nc][32] output tile
+constexpr int DT_P = 20;                // row pitch (floats) of a wave's 16-anchor staging tiles: 16-byte aligned rows
+constexpr int DT_WT = (2 * 16 + 4) * DT_P;   // floats of LDS per wave
 
 __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbl = smem;                                       // box panel: 1 chunk x 1 block
   char* wcl = smem + 1024;                                // cls panel: kch x nbc blocks of 1 KiB
   float* biasl = (float*)(wcl + (size_t)a.kch * a.nbc * 1024);       // [16] box | [nbc*16] cls
-  float* ytile = biasl + 16 + a.nbc * 16;                 // [4 waves][4+nc][DT_LD]
-  char* wb3l = (char*)(ytile + (size_t)4 * (4 + a.nc) * DT_LD);      // box 3x3 panel: 5 K chunks x 1 block of 1 KiB (+ its bias[16])
+  float* ytile = biasl + 16 + a.nbc * 16;                 // [4 waves][DT_WT floats]: per wave two 16 x DT_P class tiles (ping-pong) + one 4 x DT_P box tile
+  char* wb3l = (char*)(ytile + (size_t)4 * DT_WT);      // box 3x3 panel: 5 K chunks x 1 block of 1 KiB (+ its bias[16])
   float* bias3l = (float*)(wb3l + 5 * 1024);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,14 +50,39 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tb, 0, a.tb_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tc, 0, a.tc_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, a.feat_bytes, 0x00020000);
-  float* yt = ytile + (size_t)wave * (4 + a.nc) * DT_LD;
+  float* yt = ytile + (size_t)wave * DT_WT;               // [0, 16 P) and [16 P, 32 P): class tiles, [32 P, 36 P): box tile
   const char* wlane_b = wbl + lane * 16;
   const char* wlane_c = wcl + lane * 16;
   const int boff = (8 * g < a.c2) ? g * 16 : MGDT_OOB;    // box input: one K chunk, pieces past c2 are zero
   const int r4 = 16;                                      // 4 * reg_max
 
+  // A wave's results leave through small LDS tiles as 16-byte runs along the anchor axis of y (round 3: one 16 classes x 16 anchors tile per MFMA block instead
+  // of the whole [4+nc][32] tile: 9 KB of LDS per workgroup instead of 44, four workgroups per CU instead of two); the best class of an anchor is kept as a
+  // running (score, class) pair per lane over its own classes and combined over the four lanes of the anchor at the end (first maximal class, ops.py:225-226).
+  const bool vec_ok = (a.HW & 3) == 0 && (a.a_off & 3) == 0 && (a.a_total & 3) == 0 && ((uintptr_t)a.y & 15) == 0;
+  auto wave_sync = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // tile rows [row0, row0 + nrow) of 16 anchors starting at anchor an0 of image n -> y (lane = (row, 4 anchors))
+  auto flush = [&](const float* tile, int nrow, int row0, int n, int an0) __attribute__((always_inline)) {
+    const int row = lane >> 2, q = (lane & 3) * 4;
+    if (row < nrow && row0 + row < 4 + a.nc) {
+      float* dst = a.y + ((size_t)n * (4 + a.nc) + row0 + row) * a.a_total + a.a_off + an0 + q;
+      const float* src = tile + row * DT_P + q;
+      if (vec_ok) { if (an0 + q < a.HW) *(f32x4*)dst = *(const f32x4*)src; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (an0 + q + e < a.HW) dst[e] = src[e];
+      }
+    }
+  };
+  int flip = 0;
   for (int unit = blockIdx.x * 4 + wave; unit < a.units; unit += gridDim.x * 4) {
     const int n = unit / a.units_per_img, a0 = (unit - n * a.units_per_img) * 32;
+    float bs[2] = {-1.f, -1.f};
+    int bcl[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int an = a0 + u * 16 + r;
@@ -113,7 +139,12 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
       const float ax = (float)ox + 0.5f, ay = (float)oy + 0.5f;            // make_anchors offset 0.5 (tal.py:476-488)
       const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;       // dist2bbox (tal.py:491-500), then * stride (head.py:176)
       const float comp = g == 0 ? (x1 + x2) / 2.f * a.stride : g == 1 ? (y1 + y2) / 2.f * a.stride : g == 2 ? (x2 - x1) * a.stride : (y2 - y1) * a.stride;
-      yt[g * DT_LD + u * 16 + r] = comp;
+      {
+        float* bt = yt + 32 * DT_P;
+        bt[g * DT_P + r] = comp;
+        wave_sync();
+        flush(bt, 4, 0, n, a0 + u * 16);
+      }
       // ---- class branch
       for (int nb = 0; nb < a.nbc; ++nb) {
         f32x4 acc = *(const f32x4*)(biasl + 16 + nb * 16 + 4 * g);
@@ -125,45 +156,36 @@ __global__ __launch_bounds__(DT_THREADS) void detect_tail_kernel(const DtArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) lc[j] = (float)(bf16)acc[j];
         bstore4<bf16>(frs, c < a.nc ? (uint32_t)fo + (uint32_t)((r4 + c) * 2) : (uint32_t)MGDT_OOB, f32x4{lc[0], lc[1], lc[2], lc[3]});
+        float* ct = yt + flip * 16 * DT_P;               // ping-pong: the previous block's tile may still be on its way out of the other half
+        flip ^= 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c + j < a.nc) yt[(4 + c + j) * DT_LD + u * 16 + r] = fast_sigmoid(lc[j]);
+        for (int j = 0; j < 4; ++j) {
+          const float sg = fast_sigmoid(lc[j]);
+          ct[(4 * g + j) * DT_P + r] = sg;
+          if (c + j < a.nc && sg > bs[u]) { bs[u] = sg; bcl[u] = c + j; }       // classes come in ascending order: the first maximal one stays
+        }
+        wave_sync();
+        flush(ct, 16, 4 + nb * 16, n, a0 + u * 16);
       }
     }
-    // the wave's [4+nc][32] tile -> y rows (128-byte runs along the anchor axis); a wave's LDS accesses complete in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (a.best && lane < 32 && a0 + lane < a.HW) {
-      // best class of my anchor (first maximal score, ops.py:225-226) from the tile: the NMS key ((~score bits) << 32 | anchor * nc + class), so
-      // that mgdt_nms_fwd does not have to scan the 80 score rows of y again
-      const float* col = yt + 4 * DT_LD + lane;
-      float bs = col[0];
-      int bc = 0;
-      for (int c = 1; c < a.nc; ++c) {
-        const float v = col[c * DT_LD];
-        if (v > bs) { bs = v; bc = c; }
+    if (a.best) {
+      // best class of an anchor = the best of its four lanes (r, g = 0..3): higher score, then lower class; lane (r, 0) writes the NMS key
+      // ((~score bits) << 32 | anchor * nc + class), so that mgdt_nms_fwd does not have to scan the 80 score rows of y again
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const float os = __shfl_xor(bs[u], off, 64);
+          const int oc = __shfl_xor(bcl[u], off, 64);
+          if (os > bs[u] || (os == bs[u] && oc < bcl[u])) { bs[u] = os; bcl[u] = oc; }
+        }
+        if (g == 0 && a0 + u * 16 + r < a.HW) {
+          const unsigned an = (unsigned)(a.a_off + a0 + u * 16 + r);
+          a.best[(size_t)n * a.a_total + an] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(bs[u])) << 32) | (unsigned long long)(an * (unsigned)a.nc + (unsigned)bcl[u]);
+        }
       }
-      const unsigned an = (unsigned)(a.a_off + a0 + lane);
-      a.best[(size_t)n * a.a_total + an] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(bs)) << 32) | (unsigned long long)(an * (unsigned)a.nc + (unsigned)bc);
     }
-    float* yo = a.y + (size_t)n * (4 + a.nc) * a.a_total + a.a_off + a0;
-    if (a0 + 32 <= a.HW && ((a.a_off + a0) & 3) == 0 && (a.a_total & 3) == 0 && ((uintptr_t)a.y & 15) == 0) {
-      // 16-byte stores: lane = (row of 8, 4 consecutive anchors) - a quarter of the store instructions of the 4-byte form, which was store-issue bound
-      // (84 rows x 32 anchors x 4 B per unit = 69 MB of y per batch through dword stores)
-      const int c4 = (lane & 7) * 4, rs = lane >> 3;
-      for (int row = rs; row < 4 + a.nc; row += 8) {
-        const float* src = yt + row * DT_LD + c4;
-        *(f32x4*)(yo + (size_t)row * a.a_total + c4) = f32x4{src[0], src[1], src[2], src[3]};
-      }
-    } else {
-      const int col = lane & 31, rsel = lane >> 5;
-      for (int row = rsel; row < 4 + a.nc; row += 2)
-        if (a0 + col < a.HW) yo[(size_t)row * a.a_total + col] = yt[row * DT_LD + col];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();                                           // the last tiles have been read before the next unit writes them
   }
 }
 
@@ -204,7 +226,7 @@ extern "C" int mgdt_detect_tail_fwd(const mgdt_view* tb, const mgdt_view* tc, co
   a.kch = cdiv(tc->c, 32); a.nbc = cdiv(nc, 16);
   a.units_per_img = cdiv(a.HW, 32); a.units = a.N * a.units_per_img;
   a.a_off = a_off; a.a_total = a_total; a.stride = stride; a.fd_w = make_fastdiv((uint32_t)tb->w);
-  const size_t lds = 1024 + (size_t)a.kch * a.nbc * 1024 + (size_t)(16 + a.nbc * 16) * 4 + (size_t)4 * (4 + nc) * DT_LD * 4 + 5 * 1024 + 64;
+  const size_t lds = 1024 + (size_t)a.kch * a.nbc * 1024 + (size_t)(16 + a.nbc * 16) * 4 + (size_t)4 * DT_WT * 4 + 5 * 1024 + 64;
   if (lds > 150 * 1024) MGDT_FAIL(MGDT_BAD_SHAPE, "detect_tail: nc=%d needs %zu B of LDS", nc, lds);
   static size_t attr = 0;
   if (lds > 64 * 1024 && lds > attr) {
