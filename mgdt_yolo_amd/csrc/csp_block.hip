@@ -38,6 +38,7 @@ struct CspArgs {
   int chain_words;                     // MSPA: 16-byte words of the chain blob's weight part
   unsigned long long* dbg;             // MGDT_CSP_DBG: 8 wall-clock stamps (10 ns units) per workgroup
   int pool_gst;                        // back phase: waves per cout block = pool slots per tile (1 when there are >= 8 cout blocks)
+  FastDiv fd_rw, fd_tw, fd_tx, fd_tpi; // table phase: division by region width / tile width / tiles per row / tiles per image without the ~40-instruction sequence
 };
 
 constexpr int CSP_THREADS = 512;
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(CSP_THREADS, ((WD <= 16 || (WD == 32 && MODE == 1))
   const int tlin = (v & 7) * a.per_xcd + (v >> 3);
   if ((v >> 3) >= a.per_xcd || tlin >= a.total_tiles) return;    // uniform per workgroup: no barrier is skipped by a part of it
   const int tpi = a.tiles_x * a.tiles_y;
-  const int n = tlin / tpi, trem = tlin - n * tpi;
-  const int ty0 = (trem / a.tiles_x) * a.TH, tx0 = (trem % a.tiles_x) * a.TW;
+  const int n = (int)fdiv((uint32_t)tlin, a.fd_tpi), trem = tlin - n * tpi;
+  const int tyi = (int)fdiv((uint32_t)trem, a.fd_tx);
+  const int ty0 = tyi * a.TH, tx0 = (trem - tyi * a.tiles_x) * a.TW;
   const int RP = a.RH * a.RW, TP = a.TH * a.TW;
   auto stamp = [&](int k) __attribute__((always_inline)) { if (a.dbg && tid == 0) a.dbg[(size_t)tlin * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(CSP_THREADS, ((WD <= 16 || (WD == 32 && MODE == 1))
 
   // ---- tables, zero fill, chain weights
   for (int q = tid; q < a.RPA; q += CSP_THREADS) {
-    const int ry = q / a.RW, rx = q - ry * a.RW;
+    const int ry = (int)fdiv((uint32_t)q, a.fd_rw), rx = q - ry * a.RW;
     const int iy = ty0 - a.halo + ry, ix = tx0 - a.halo + rx;
     const bool in = q < RP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     goff[q] = in ? n * a.xsn + iy * a.xsh + ix * a.xsw : MGDT_OOB;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(CSP_THREADS, ((WD <= 16 || (WD == 32 && MODE == 1))
     ctab[q] = (q < RP && (unsigned)cy < (unsigned)a.TH && (unsigned)cx < (unsigned)a.TW) ? (short)(cy * a.TW + cx) : (short)-1;
   }
   for (int t = tid; t < a.TPA; t += CSP_THREADS) {
-    const int cy = t / a.TW, cx = t - cy * a.TW;
+    const int cy = (int)fdiv((uint32_t)t, a.fd_tw), cx = t - cy * a.TW;
     yoff[t] = t < TP ? n * a.ysn + (ty0 + cy) * a.ysh + (tx0 + cx) * a.ysw : MGDT_OOB;
   }
   {
@@ -491,6 +493,8 @@ extern "C" int mgdt_csp_block_fwd(int mode, const mgdt_view* x, const void* fron
   a.TH = g.TH; a.TW = g.TW; a.halo = g.halo; a.RH = g.RH; a.RW = g.RW; a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   a.RPA = g.RPA; a.TPA = g.TPA; a.PS = g.PS; a.CS = g.CS;
   a.total_tiles = a.N * g.tiles_x * g.tiles_y;
+  a.fd_rw = make_fastdiv((uint32_t)g.RW); a.fd_tw = make_fastdiv((uint32_t)g.TW); a.fd_tx = make_fastdiv((uint32_t)g.tiles_x);
+  a.fd_tpi = make_fastdiv((uint32_t)(g.tiles_x * g.tiles_y));
   a.per_xcd = cdiv(a.total_tiles, 8);
   const int grid = 8 * a.per_xcd;
   hipStream_t st = (hipStream_t)s;
