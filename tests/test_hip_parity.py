@@ -1400,6 +1400,34 @@ def test_side_stream_branch_is_the_same_forward(name, dtype):
             assert all(torch.equal(a, b) for a, b in zip(out, r))
 
 
+@pytest.mark.parametrize('name', ['mspa_c2f_gd_yolov8', 'yolov8'])
+@pytest.mark.parametrize('nc', [4, 36])
+def test_detect_tail_class_counts_levels_and_ragged_maps(name, nc):
+    """mgdt_detect_tail_fwd (round 3: 16 x 16 staging tiles per MFMA block, best class carried in registers) against the unfused head - class counts
+    that are not a multiple of the 16-class MFMA block, one and three levels (anchor offsets), maps whose anchor count is not a multiple of the
+    32-anchor unit: decoded boxes / scores within 1e-4 px / 1e-6, raw maps identical, and the NMS keys equal to a scan of y (first maximal class)."""
+    from mgdt_yolo_amd import ops
+    m = build_model(name, torch.bfloat16, nc=nc)
+    for shape in ((2, 320, 256), (1, 224, 352)):
+        x = seeded_images(*shape, seed=5).to(DEV).to(torch.bfloat16)
+        with torch.no_grad():
+            y1, f1 = m(x)
+            keys = ops._best_keys_of(y1, y1.shape[0], y1.shape[2])
+            ops.FUSED_DETECT_TAIL = False
+            try:
+                y0, f0 = m(x)
+            finally:
+                ops.FUSED_DETECT_TAIL = True
+        assert keys is not None, 'the fused tail must hand its keys to NMS'
+        d = (y1 - y0).abs()
+        assert d[:, :4].max().item() < 1e-4 and d[:, 4:].max().item() < 1e-6, (shape, d[:, :4].max().item(), d[:, 4:].max().item())
+        assert all(torch.equal(a, b) for a, b in zip(f1, f0))
+        best, cls = y1[:, 4:, :].max(1)
+        anchors = torch.arange(y1.shape[2], device=y1.device)[None, :]
+        ref = ((0xFFFFFFFF - (best.contiguous().view(torch.int32).long() & 0xFFFFFFFF)) << 32) | (anchors * nc + cls)
+        assert torch.equal(keys, ref), shape
+
+
 def test_graph_instances_in_flight_match_their_serial_replays():
     """bench.py --inflight: several captured instances of the inference step (forward + NMS, each with its parallel branch) replayed
     concurrently on their own streams.  Round 2 saw wrong values here (conv_igemm -> bilinear); the cause was packed-fp32 VALU arithmetic
