@@ -75,11 +75,22 @@ __global__ __launch_bounds__(256 * WS, 1) void conv3x3_lds_kernel(const C3Args a
     tab[p] = tap < 9 ? ((tap / 3) * RW + (tap % 3)) * a.XP + cp * PB : 0;       // padding pieces carry zero weights: any in-range address
   }
   constexpr int WV = WB / 16;                                       // 16-byte vectors per weight block
-  for (int i = tid; i < a.nchunks * NBW * WV; i += NTHR) {
-    const int kc = i / (NBW * WV), rem = i - kc * NBW * WV, bw = rem / WV, ln = rem % WV;
-    const bool ok = nb0 + bw < a.NTtot;
-    const uint4 v = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * WV + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
-    *(uint4*)(wl + (size_t)i * 16) = v;
+  {
+    // eight requests of a thread in flight before its first LDS store (the plain copy loop waited for every load in turn)
+    const int total = a.nchunks * NBW * WV;
+    for (int i0 = tid; i0 < total; i0 += 8 * NTHR) {
+      uint4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + u * NTHR, total - 1);
+        const int kc = i / (NBW * WV), rem = i - kc * NBW * WV, bw = rem / WV, ln = rem % WV;
+        const bool ok = nb0 + bw < a.NTtot;
+        t[u] = ok ? *(const uint4*)(a.wpk + ((size_t)(kc * a.NTtot + nb0 + bw) * WV + ln) * 16) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * NTHR < total) *(uint4*)(wl + (size_t)(i0 + u * NTHR) * 16) = t[u];
+    }
   }
   const int nbw0 = nb0 + wcol * NBH;                                 // this wave's first cout block
   f32x4 bias[NBH], osc[Q8 ? NBH : 1];

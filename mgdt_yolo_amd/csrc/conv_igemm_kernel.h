@@ -150,11 +150,24 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const ConvArgs a) {
     const int nc = min(a.seg_chunks, a.nchunks - c0);
     const int nblk = nc * NT;  // WB-byte blocks
     constexpr int V = WB / 16;
-    for (int i = tid; i < nblk * V; i += nthr) {
-      int blk = i / V, l = i % V;
-      int kc = blk / NT, nt = blk % NT;
-      const uint4* src = (const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * WB) + l;
-      ((uint4*)(wlds + (long)blk * WB))[l] = *src;
+    // UB requests of a thread are in flight before its first LDS store (a plain copy loop waited for every load in turn: up to 18 L2 round trips in
+    // front of a persistent workgroup's first tile for a 144 KiB panel)
+    constexpr int UB = MULTI ? 2 : 8;
+    const int total = nblk * V;
+    for (int i0 = tid; i0 < total; i0 += UB * nthr) {
+      uint4 t[UB];
+      int dst[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = min(i0 + u * nthr, total - 1);
+        const int blk = i / V, l = i % V;
+        const int kc = blk / NT, nt = blk % NT;
+        t[u] = *((const uint4*)(a.wpk + ((long)(c0 + kc) * a.NTtot + nb0 + nt) * WB) + l);
+        dst[u] = i0 + u * nthr < total ? blk * (WB / 16) + l : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (dst[u] >= 0) ((uint4*)wlds)[dst[u]] = t[u];
     }
   };
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);

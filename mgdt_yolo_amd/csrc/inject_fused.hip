@@ -170,8 +170,20 @@ __global__ __launch_bounds__(64 * TH) void conv1x1_inject_conv_kernel(const InjC
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  for (int i = tid; i < KC * NB * 64; i += THREADS) ((uint4*)wl)[i] = ((const uint4*)a.wpk)[i];
-  for (int i = tid; i < KC2 * NB2 * 64; i += THREADS) ((uint4*)w2l)[i] = ((const uint4*)A.w2)[i];
+  {
+    // both weight panels: every 16-byte request is issued before the first LDS store (the copy loops waited for each load in turn - eight L2 round
+    // trips in front of a persistent workgroup's first patch)
+    constexpr int W1 = KC * NB * 64, W2 = KC2 * NB2 * 64, N1 = (W1 + THREADS - 1) / THREADS, N2 = (W2 + THREADS - 1) / THREADS;
+    uint4 t1[N1], t2[N2];
+#pragma unroll
+    for (int u = 0; u < N1; ++u) t1[u] = ((const uint4*)a.wpk)[min(tid + u * THREADS, W1 - 1)];
+#pragma unroll
+    for (int u = 0; u < N2; ++u) t2[u] = ((const uint4*)A.w2)[min(tid + u * THREADS, W2 - 1)];
+#pragma unroll
+    for (int u = 0; u < N1; ++u) if (tid + u * THREADS < W1) ((uint4*)wl)[tid + u * THREADS] = t1[u];
+#pragma unroll
+    for (int u = 0; u < N2; ++u) if (tid + u * THREADS < W2) ((uint4*)w2l)[tid + u * THREADS] = t2[u];
+  }
   if (GCONV) {
     for (int i = tid; i < NB * 2 * 2 * 64; i += THREADS) ((uint4*)hgT)[i] = make_uint4(0u, 0u, 0u, 0u);     // unused source slots must stay finite (x 0 weights)
   }
