@@ -179,6 +179,13 @@ def roofline_of(prof_rows, reps, step_ms, graph, args):
         f['ms'] += ms; f['n'] += cnt; f['flops'] += meta['flops'] * cnt; f['bytes'] += meta['bytes'] * cnt
         f['shapes'].append((ms / reps, cnt // reps, list(shape), meta))
     name, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
+    # two families are now within a few percent of each other (convolutions 0.29 ms, block kernels 0.28 ms of the eager step): run-to-run noise must not
+    # flip the reported kernel, so the convolution family - the one the PMC traffic figure and every earlier round refer to - keeps the title while it is
+    # within 5 % of the largest share
+    for keep in ('conv2d_fwd', 'conv2d_fp8_fwd'):
+        if keep in fam and fam[keep]['ms'] >= 0.95 * f['ms']:
+            name, f = keep, fam[keep]
+            break
     # eager launches start on an idle queue (Python issues slower than the GPU drains), which adds a ramp to every event pair; the graph
     # replay of the timed region has no such gaps.  Rescale the eager per-launch times so that they sum to the measured replay step.
     scale = step_ms / total_ms if graph else 1.0
